@@ -1,0 +1,283 @@
+/*
+ * ironcortex_hip.h — C ABI of libironcortex_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the IronCortex inner-step hot path (gate -> router ->
+ * region cells -> KWTA).  The reference has no FFI of its own: the path sits
+ * behind plain Python methods on nn.Modules.  Every entry
+ * point below names the reference method(s) it replaces (file:line into the
+ * reference tree) and is what a ctypes binding on the reference side would
+ * call.
+ *
+ * Conventions
+ *   - all tensors are dense, row-major, fp32 unless stated; pointers are
+ *     DEVICE pointers; NULL is allowed only where a field says so.
+ *   - S = independent streams (sequences), R = regions, d = width, E = edges.
+ *   - the library never allocates, never synchronises the stream and never
+ *     throws: a call returns 0 or a negative IC_E* code and ic_last_error()
+ *     gives the text for the calling thread.
+ *   - masks are uint8 (0/1), dt counters int32.
+ */
+#ifndef IRONCORTEX_HIP_H
+#define IRONCORTEX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ic_stream_t; /* a hipStream_t (0 = default stream) */
+
+enum {
+  IC_OK = 0,
+  IC_EINVAL = -1,  /* bad shape / NULL pointer / unsupported size */
+  IC_ELAUNCH = -2, /* hipGetLastError() after a launch */
+  IC_EDEVICE = -3  /* no gfx950 device / wrong arch */
+};
+
+/* region-phase flags */
+enum {
+  IC_F_AFD = 1 << 0,        /* enable_adaptive_filter_dynamics (region.py:192-212) */
+  IC_F_RT = 1 << 1,         /* enable_radial_tangential_updates (region.py:218-235) */
+  IC_F_PRED = 1 << 2,       /* use_predictive_trace (region.py:140-146,173-175) */
+  IC_F_NOKWTA = 1 << 3,     /* disable_kwta (region.py:238) */
+  IC_F_KWTA_SOFT = 1 << 4,  /* soft KWTA during warm-up (region.py:244-246) */
+  IC_F_NOISE_VEC = 1 << 5,  /* afd_noise_mode == "vector" (region.py:63-68) */
+  IC_F_NORM_IN = 1 << 6,    /* apply shared norm_in + sensor add (model.py:198-204) */
+  IC_F_NEED_GRAD = 1 << 7   /* write the saved-for-backward buffers */
+};
+
+/* router flags */
+enum {
+  IC_RF_PRECISION = 1 << 0 /* enable_precision_routed_messages (gate.py:292-318) */
+};
+
+const char* ic_last_error(void);
+/* Fills name (<= cap bytes) with the device's gcnArchName; returns IC_OK only on gfx950. */
+int ic_device_check(char* name, int cap);
+int ic_version(void);
+
+/* ------------------------------------------------------------------ region phase
+ * One inner step's region work for S streams x R regions in 4 launches:
+ *   prologue   x = RMSNorm_r( RMSNorm_in(M[r] (+sensor)) + pred )     region.py:173-177, model.py:198-204
+ *   rkv        r,k,v GEMVs, time rotation of v, decay fast-forward,
+ *              WKV (or AFD/Kalman) state update, y                     region.py:178-216, 94-135
+ *   out        h_pre = x + W_o y   (or x + radius * W_o dir)           region.py:218-237
+ *   finish     active: h = KWTA(h_pre), pred <- 0, dt <- 0
+ *              inactive: H = 0, pred <- a*pred + (1-a)*M, dt += 1      region.py:137-146,238-249, model.py:275-290
+ * Regions are gathered by mask[S,R]; weights stay in place (no stacking copy).
+ */
+typedef struct ic_region_args {
+  int32_t S, R, d;
+  int32_t m_time;     /* rotated channel pairs of v (region.py:87) */
+  int32_t kwta_k;     /* winners; <=0 -> zeros; clamped to d */
+  int32_t flags;      /* IC_F_* */
+  int32_t sensor_idx; /* regions that add the sensor vector (-1: none) */
+  int32_t motor_idx;
+  int32_t rows_fwd;   /* rows of W per workgroup in the forward GEMVs (multiple of 8; 0 -> 8) */
+  float step_pos;     /* inner-step position in [0,1] (model.py:289) */
+  float kwta_temp;    /* soft-KWTA temperature */
+  double pred_alpha;  /* 0.95 (region.py:140); a double so that fp32(1-alpha) matches Python */
+  /* parameters */
+  const float* W;         /* [R,4,d,d]  r,k,v,o  (region.py:56-59) */
+  const float* norm_w;    /* [R,d]      region.norm.weight */
+  const float* raw_decay; /* [R,d]      region.py:62 */
+  const float* norm_in_w; /* [d] or NULL (model.norm_in.weight) */
+  const float* W_time;    /* [m_time]   region.py:88-91 */
+  const float* pn_param;  /* [R] or [R,d]  AFD only */
+  const float* on_param;  /* [R] or [R,d]  AFD only */
+  const float* rpn_param; /* [R]  RT only */
+  const float* ron_param; /* [R]  RT only */
+  /* inputs */
+  const float* M;      /* [S,R,d] router messages (or x_in when !IC_F_NORM_IN) */
+  const float* sensor; /* [S,d] or NULL */
+  const uint8_t* mask; /* [S,R] active regions */
+  const float *num, *den, *var, *pred; /* [S,R,d]; var AFD only; pred if IC_F_PRED */
+  const float *radius, *radius_var;    /* [S,R] RT only */
+  const float* surprise;               /* [S,R] AFD only */
+  const int32_t* dt;                   /* [S,R] */
+  /* outputs */
+  float *H, *num_o, *den_o, *var_o, *pred_o; /* [S,R,d] */
+  float *radius_o, *radius_var_o, *surprise_o; /* [S,R] */
+  float *last_dir, *last_norm; /* [S,R,d],[S,R] RT telemetry, may be NULL */
+  int32_t* dt_o;
+  /* saved for backward / inter-kernel workspace (always required) */
+  float* x;     /* [S,R,d] normalised input */
+  float* u1;    /* [S,R,d] x_in + pred */
+  float* inv_s; /* [S,R,2] 1/rms of the two norms */
+  float *r_s, *k_s, *v_s; /* [S,R,d] sigmoid(r), k, rotated v */
+  float* y;     /* [S,R,d] */
+  float* hpre;  /* [S,R,d] pre-KWTA activations */
+  float* gate;  /* [S,R,d] KWTA multiplier (0/1 hard) */
+  float* ynorm; /* [S,R]  RT only */
+  float* sterm; /* [S,R,d] AFD surprise terms */
+} ic_region_args;
+
+int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream);
+
+/* Backward of the same phase (autograd of region.py:168-249 + model.py:198-204,275-290).
+ * Weight gradients are NOT formed here: the per-step gradient vectors are written to a
+ * tape slot and ic_region_wgrad() forms dW once per backward pass. */
+typedef struct ic_region_bwd_args {
+  ic_region_args f; /* same dims/params/inputs/saved as the forward call (outputs unused) */
+  /* incoming gradients, NULL = zero */
+  const float *gH, *gnum_o, *gden_o, *gvar_o, *gpred_o; /* [S,R,d] */
+  const float *gradius_o, *gradius_var_o;               /* [S,R] */
+  /* outgoing gradients */
+  float *gM, *gnum, *gden, *gvar, *gpred; /* [S,R,d] */
+  float *gradius, *gradius_var;           /* [S,R] */
+  float* gsens;                           /* [S,2,d] sensor/motor contributions, or NULL */
+  /* per-row parameter gradients (host reduces over S and accumulates) */
+  float *g_norm_w_rows, *g_raw_decay_rows, *g_norm_in_rows; /* [S,R,d] */
+  float *g_pn_rows, *g_on_rows; /* [S,R,d] AFD */
+  float* g_rnoise_rows;         /* [S,R,2] RT: d/d rpn_param, d/d ron_param */
+  /* tape slot for the deferred weight gradient */
+  float* tape_g; /* [S,R,4,d] gradient vectors of the r,k,v,o pre-activations */
+  float* tape_x; /* [S,R,d]   operand of r,k,v (the normalised input x) */
+  float* tape_o; /* [S,R,d]   operand of o (y, or dir under RT) */
+  /* workspace */
+  float* ghpre;   /* [S,R,d] gradient w.r.t. the pre-KWTA activations */
+  float* gy;      /* [S,R,d] gradient w.r.t. y */
+  float* slab;    /* [nslab,S,R,d] partial transposed products; nslab = ic_region_bwd_nslab(d) */
+  float* slab_rt; /* [nslab,S,R] RT only: partial d/d radius' */
+} ic_region_bwd_args;
+
+int ic_region_phase_bwd(const ic_region_bwd_args* a, ic_stream_t stream);
+/* number of row slabs the backward kernels use for width d (also used by the router backward) */
+int ic_bwd_nslab(int32_t d);
+
+/* dW[r,j] (+)= sum over tape slots t, streams s with mask: g[t,s,r,j,:] (x) operand[t,s,r,:]
+ * (operand = x for j<3, tape_o for j==3).  One launch per backward pass.
+ * visited[t]==0 slots are skipped.  touched[r] is set to 1 for every region that received
+ * a contribution.  replaces the autograd accumulation into r_lin/k_lin/v_lin/o_lin.weight.grad. */
+typedef struct ic_wgrad_region_args {
+  int32_t T, S, R, d;
+  const float* tape_g;    /* [T,S,R,4,d] */
+  const float* tape_x;    /* [T,S,R,d] */
+  const float* tape_o;    /* [T,S,R,d] */
+  const uint8_t* mask;    /* [T,S,R] */
+  const uint8_t* visited; /* [T] */
+  float* gW;              /* [R,4,d,d] accumulated in place */
+  uint8_t* touched;       /* [R] */
+} ic_wgrad_region_args;
+int ic_region_wgrad(const ic_wgrad_region_args* a, ic_stream_t stream);
+
+/* ------------------------------------------------------------------ router
+ * Router.aggregate, per-edge transforms in place (gate.py:251-335).  Edges are stored
+ * dst-major exactly as Router.__init__ builds them (gate.py:124-133): edge ids
+ * dst_off[r]..dst_off[r+1]-1 arrive at r, src[e] is the sender.  widx[e] selects the
+ * weight matrix (e for per_edge, direction 0..5 for by_direction, gate.py:274-277).
+ * ebias[e] = 1 + fb_alpha * b_e (gate.py:284-290) is computed by the caller.
+ */
+typedef struct ic_router_args {
+  int32_t S, R, d, E, flags;
+  const int32_t* dst_off; /* [R+1] */
+  const int32_t* src;     /* [E] */
+  const int32_t* widx;    /* [E] */
+  const float* W;         /* [nW,d,d] */
+  const float* ebias;     /* [E] */
+  const float* key_W;     /* [nW,d,d]  precision only */
+  const float* query_W;   /* [R,d,d]   precision only */
+  const float* raw_P;     /* [nW,d]    precision only */
+  const float* H;         /* [S,R,d] */
+  const uint8_t* mask_prev; /* [S,R] */
+  float* M;               /* [S,R,d] out */
+  /* saved / workspace (precision only; may be NULL otherwise) */
+  float* msg;  /* [S,E,d] biased messages */
+  float* keyv; /* [S,E,d] key vectors */
+  float* q;    /* [S,R,d] queries */
+  float* wgt;  /* [S,E]  routing weights (0 for inactive edges) */
+} ic_router_args;
+int ic_router_fwd(const ic_router_args* a, ic_stream_t stream);
+
+typedef struct ic_router_bwd_args {
+  ic_router_args f;
+  const int32_t* src_off;   /* [R+1] CSR by sender: out-edges of each region */
+  const int32_t* src_edges; /* [E] edge ids grouped by sender */
+  const float* gM; /* [S,R,d] */
+  float* gH;       /* [S,R,d] */
+  float* g_ebias_part; /* [nslab,S,E] partial sums, host reduces over nslab and S */
+  float* g_rawP_rows;  /* [S,E,d] precision only */
+  /* tape slot for deferred weight gradients */
+  float* tape_gmsg; /* [S,E,d] gradient w.r.t. the raw message W_e h_src (ebias folded in) */
+  float* tape_gkey; /* [S,E,d] precision only */
+  float* tape_gq;   /* [S,R,d] precision only */
+  float* tape_H;    /* [S,R,d] copy of H */
+  uint8_t* tape_eact; /* [S,E] 1 if edge was active */
+  uint8_t* tape_qact; /* [S,R] precision only: 1 if the region had an active incoming edge */
+  /* workspace */
+  float* gHd;    /* [S,R,d] precision only: direct d/dH_dst */
+  float* slab;   /* [nslab,S,E,d], nslab = ic_bwd_nslab(d) */
+  float* slab_q; /* [nslab,S,R,d] precision only */
+} ic_router_bwd_args;
+int ic_router_bwd(const ic_router_bwd_args* a, ic_stream_t stream);
+
+typedef struct ic_wgrad_edge_args {
+  int32_t T, S, R, d, E, nW, which; /* which: 0 = W_edge, 1 = key_W, 2 = query_W */
+  const int32_t* dst_off;
+  const int32_t* src;
+  const int32_t* widx;
+  const float* tape_g;      /* [T,S,E,d]  (which==2: [T,S,R,d]) */
+  const float* tape_H;      /* [T,S,R,d] */
+  const uint8_t* tape_eact; /* [T,S,E]    (which==2: [T,S,R] row-active) */
+  const uint8_t* visited;   /* [T] */
+  float* gW;                /* [nW,d,d] (which==2: [R,d,d]) accumulated in place */
+  uint8_t* touched;         /* [nW] or [R] */
+} ic_wgrad_edge_args;
+int ic_router_wgrad(const ic_wgrad_edge_args* a, ic_stream_t stream);
+
+/* ------------------------------------------------------------------ gate
+ * Gate.score_regions (gate.py:54-68): scores = w1*mean|H| + w2*gain_ema + w3*focus
+ *   - w4*homeo + t5 + t6 with t5 = fp32(w5*value_bias), t6 = fp32(w6*u_mean) from the host. */
+typedef struct ic_gate_args {
+  int32_t S, R, d;
+  int32_t sensor_idx, motor_idx;
+  int32_t k_total;   /* k_active + burst (before the forced pair is subtracted) */
+  int32_t force_io;  /* io_force_on */
+  float w1, w2, w3, w4;
+  float t5, t6;
+  const float* H;          /* [S,R,d] */
+  const float* gain_ema;   /* [R] */
+  const float* homeo;      /* [R] */
+  const uint8_t* focus_any; /* [S] 1 if any focus bit set (gate.py:42-52) */
+  const int32_t* nbr_off;  /* [R+1] adjacency CSR */
+  const int32_t* nbr;      /* [nnz] */
+  float* scores;           /* [S,R] out */
+  uint8_t* mask;           /* [S,R] out */
+} ic_gate_args;
+int ic_gate_scores(const ic_gate_args* a, ic_stream_t stream);
+/* Gate.select_k + nms_topk (gate.py:70-87, utils.py:107-124).  Total order: score
+ * descending, index ascending (stable); quirks of the greedy walk are reproduced. */
+int ic_gate_select(const ic_gate_args* a, ic_stream_t stream);
+
+/* ------------------------------------------------------------------ primitives
+ * KWTA (utils.py:38-60) on `rows` rows of width d: threshold = k-th largest |x|,
+ * ties keep extra units.  gate receives the multiplier (for the backward). */
+int ic_kwta_fwd(const float* x, float* y, float* gate, int32_t rows, int32_t d, int32_t k,
+                int32_t soft, float temp, ic_stream_t stream);
+/* gx = gy * gate (+ soft-mode threshold terms) */
+int ic_kwta_bwd(const float* x, const float* gate, const float* gy, float* gx, int32_t rows,
+                int32_t d, int32_t k, int32_t soft, float temp, ic_stream_t stream);
+/* RMSNorm (utils.py:20-35): y = w * x / sqrt(mean(x^2)+eps) */
+int ic_rmsnorm_fwd(const float* x, const float* w, float* y, float* inv_s, int32_t rows, int32_t d,
+                   float eps, ic_stream_t stream);
+int ic_rmsnorm_bwd(const float* x, const float* w, const float* inv_s, const float* gy, float* gx,
+                   float* gw_rows, int32_t rows, int32_t d, ic_stream_t stream);
+
+/* Per-region forward-forward goodness g[b,r] = mean_d H[b,r,:]^2 (training.py:127-128,
+ * utils.py:159-162) and its backward gH = gg * 2 H / d. */
+int ic_goodness_fwd(const float* H, float* g, int32_t rows, int32_t d, ic_stream_t stream);
+int ic_goodness_bwd(const float* H, const float* gg, float* gH, int32_t rows, int32_t d,
+                    ic_stream_t stream);
+
+/* Hebbian edge nudges (training.py:147-156,240-243):
+ * W[widx[e]] += sum_b coef[b,e] * outer(H[b,dst_e], H[b,src_e]),
+ * coef = 1e-3*gain[dst] when both ends were active in sample b and gain>0, else 0. */
+int ic_hebbian_rank1(float* W, const int32_t* dst_of_edge, const int32_t* src, const int32_t* widx,
+                     const float* coef, const float* H, int32_t B, int32_t R, int32_t d, int32_t E,
+                     ic_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRONCORTEX_HIP_H */

@@ -1,0 +1,133 @@
+// Shared device helpers for the IronCortex gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ironcortex_hip.h"
+
+#define IC_EPS_DIV 1e-8f   // constants.py:1
+#define IC_MAX_EXP 40.0f   // constants.py:3
+#define IC_MAX_NOISE 1.0f  // constants.py:4
+#define IC_RMS_EPS 1e-5f   // utils.py:28
+
+void ic_set_error(const char* fmt, ...);
+
+#define IC_REQUIRE(cond, ...)        \
+  do {                               \
+    if (!(cond)) {                   \
+      ic_set_error(__VA_ARGS__);     \
+      return IC_EINVAL;              \
+    }                                \
+  } while (0)
+
+#define IC_LAUNCH_CHECK(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      ic_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return IC_ELAUNCH;                                                   \
+    }                                                                      \
+  } while (0)
+
+// ---- wave64 reductions (all lanes receive the result) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// torch.nn.functional.softplus (beta=1, threshold=20)
+__device__ __forceinline__ float ic_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// d softplus / dx as torch's backward computes it
+__device__ __forceinline__ float ic_softplus_grad(float x) {
+  if (x > 20.0f) return 1.0f;
+  float z = expf(x);
+  return z / (z + 1.0f);
+}
+__device__ __forceinline__ float ic_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// softplus(p).clamp_min(EPS).clamp_max(MAX_NOISE)  (region.py:100-126)
+__device__ __forceinline__ float ic_noise(float p) {
+  return fminf(fmaxf(ic_softplus(p), IC_EPS_DIV), IC_MAX_NOISE);
+}
+// derivative of ic_noise w.r.t. p (clamps pass gradient inside [min,max] inclusive)
+__device__ __forceinline__ float ic_noise_grad(float p) {
+  float s = ic_softplus(p);
+  return (s >= IC_EPS_DIV && s <= IC_MAX_NOISE) ? ic_softplus_grad(p) : 0.0f;
+}
+
+// Column ownership inside a wave for a row of width d: lane l owns float4 chunks at
+// columns 4*l + 256*j, j < DCH.  d must be a multiple of 4.
+template <int DCH>
+struct RowFrag {
+  float4 v[DCH];
+};
+
+template <int DCH>
+__device__ __forceinline__ void load_row(RowFrag<DCH>& f, const float* __restrict__ row, int d,
+                                         int lane) {
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    int c = 4 * lane + 256 * j;
+    f.v[j] = (c < d) ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int DCH>
+__device__ __forceinline__ void store_row(const RowFrag<DCH>& f, float* __restrict__ row, int d,
+                                          int lane) {
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    int c = 4 * lane + 256 * j;
+    if (c < d) *reinterpret_cast<float4*>(row + c) = f.v[j];
+  }
+}
+template <int DCH>
+__device__ __forceinline__ float dot_frag(const RowFrag<DCH>& a, const RowFrag<DCH>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    s = fmaf(a.v[j].x, b.v[j].x, s);
+    s = fmaf(a.v[j].y, b.v[j].y, s);
+    s = fmaf(a.v[j].z, b.v[j].z, s);
+    s = fmaf(a.v[j].w, b.v[j].w, s);
+  }
+  return s;
+}
+template <int DCH>
+__device__ __forceinline__ void axpy_frag(RowFrag<DCH>& acc, float a, const RowFrag<DCH>& x) {
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    acc.v[j].x = fmaf(a, x.v[j].x, acc.v[j].x);
+    acc.v[j].y = fmaf(a, x.v[j].y, acc.v[j].y);
+    acc.v[j].z = fmaf(a, x.v[j].z, acc.v[j].z);
+    acc.v[j].w = fmaf(a, x.v[j].w, acc.v[j].w);
+  }
+}
+template <int DCH>
+__device__ __forceinline__ void zero_frag(RowFrag<DCH>& f) {
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) f.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Dispatch on the number of 256-column chunks a row needs (d <= 1024).
+#define IC_DISPATCH_DCH(d, ...)                    \
+  do {                                             \
+    if ((d) <= 256) {                              \
+      constexpr int DCH = 1;                       \
+      __VA_ARGS__;                                 \
+    } else if ((d) <= 512) {                       \
+      constexpr int DCH = 2;                       \
+      __VA_ARGS__;                                 \
+    } else {                                       \
+      constexpr int DCH = 4;                       \
+      __VA_ARGS__;                                 \
+    }                                              \
+  } while (0)
+
+static inline int ic_ceil_div(int a, int b) { return (a + b - 1) / b; }

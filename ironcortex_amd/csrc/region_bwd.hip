@@ -1,0 +1,633 @@
+// Region phase, backward.  Five launches mirror the forward in reverse:
+//   fin_bwd  (wave/row)   KWTA backward -> ghpre; inactive rows: trace/state pass-through grads
+//   out_bwd  (slice x r)  W_o^T ghpre -> slabs, tape g_o / operand
+//   mid_bwd  (wave/row)   slab reduce -> gy; radial-tangential scalar chain
+//   rkv_bwd  (slice x r)  state/WKV/AFD backward per channel, W_{r,k,v}^T g -> slabs, tape
+//   pro_bwd  (wave/row)   slab reduce + residual -> two RMSNorm backwards -> gM, gpred
+// Weight gradients are deferred: see k_wgrad_region (one launch per backward pass).
+// Autograd of reference region.py:168-249, model.py:198-204,275-290.
+#include "ic_common.h"
+
+namespace {
+
+__device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int R, int r) {
+  for (int s = 0; s < S; ++s)
+    if (mask[s * R + r]) return true;
+  return false;
+}
+
+template <int DCH>
+__device__ __forceinline__ void load_opt(RowFrag<DCH>& f, const float* base, size_t off, int d,
+                                         int lane) {
+  if (base)
+    load_row(f, base + off, d, lane);
+  else
+    zero_frag(f);
+}
+
+// ---------------------------------------------------------------- finish backward
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_fin_bwd(ic_region_bwd_args b, float one_minus_alpha) {
+  const ic_region_args& a = b.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  const int d = a.d;
+  const size_t off = (size_t)row * d;
+  const bool afd = a.flags & IC_F_AFD, rt = a.flags & IC_F_RT, pred = a.flags & IC_F_PRED;
+  if (a.mask[row]) {
+    RowFrag<DCH> g, gt, h;
+    load_opt(g, b.gH, off, d, lane);
+    load_row(gt, a.gate + off, d, lane);
+    const bool soft = (a.flags & IC_F_KWTA_SOFT) && !(a.flags & IC_F_NOKWTA) && a.kwta_k > 0;
+    if (!soft) {
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        g.v[j].x *= gt.v[j].x; g.v[j].y *= gt.v[j].y; g.v[j].z *= gt.v[j].z; g.v[j].w *= gt.v[j].w;
+      }
+    } else {
+      // out_j = h_j * G_j, G_j = sigmoid((|h_j| - thr)/T) below the threshold, 1 at/above it;
+      // thr = |h_k*| carries gradient to the k-th winner (utils.py:53-58).
+      load_row(h, a.hpre + off, d, lane);
+      const float T = a.kwta_temp;
+      float gthr = 0.f, thr = 0.f;
+      float hv[4 * DCH], gv[4 * DCH], Gv[4 * DCH];
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        hv[4 * j] = h.v[j].x; hv[4 * j + 1] = h.v[j].y; hv[4 * j + 2] = h.v[j].z; hv[4 * j + 3] = h.v[j].w;
+        gv[4 * j] = g.v[j].x; gv[4 * j + 1] = g.v[j].y; gv[4 * j + 2] = g.v[j].z; gv[4 * j + 3] = g.v[j].w;
+        Gv[4 * j] = gt.v[j].x; Gv[4 * j + 1] = gt.v[j].y; Gv[4 * j + 2] = gt.v[j].z; Gv[4 * j + 3] = gt.v[j].w;
+      }
+      // threshold = smallest |h| among the winners (gate == 1)
+      float tmin = INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4 * DCH; ++e) {
+        const int c = 4 * lane + 256 * (e >> 2) + (e & 3);
+        if (c < d && Gv[e] >= 1.0f) tmin = fminf(tmin, fabsf(hv[e]));
+      }
+      thr = -wave_max(-tmin);
+#pragma unroll
+      for (int e = 0; e < 4 * DCH; ++e) {
+        const int c = 4 * lane + 256 * (e >> 2) + (e & 3);
+        float out = 0.f;
+        if (c < d) {
+          if (Gv[e] >= 1.0f) {
+            out = gv[e];
+          } else {
+            const float sp = Gv[e] * (1.0f - Gv[e]) / T;
+            const float sg = hv[e] > 0.f ? 1.f : (hv[e] < 0.f ? -1.f : 0.f);
+            out = gv[e] * (Gv[e] + hv[e] * sp * sg);
+            gthr -= gv[e] * hv[e] * sp;
+          }
+        }
+        gv[e] = out;
+      }
+      gthr = wave_sum(gthr);
+      // first element whose |h| equals the threshold receives gthr * sign(h)
+      int first = 1 << 30;
+#pragma unroll
+      for (int e = 0; e < 4 * DCH; ++e) {
+        const int c = 4 * lane + 256 * (e >> 2) + (e & 3);
+        if (c < d && Gv[e] >= 1.0f && fabsf(hv[e]) == thr) first = min(first, c);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+#pragma unroll
+      for (int e = 0; e < 4 * DCH; ++e) {
+        const int c = 4 * lane + 256 * (e >> 2) + (e & 3);
+        if (c == first) gv[e] += gthr * (hv[e] > 0.f ? 1.f : (hv[e] < 0.f ? -1.f : 0.f));
+      }
+#pragma unroll
+      for (int j = 0; j < DCH; ++j)
+        g.v[j] = make_float4(gv[4 * j], gv[4 * j + 1], gv[4 * j + 2], gv[4 * j + 3]);
+    }
+    store_row(g, b.ghpre + off, d, lane);
+  } else {
+    RowFrag<DCH> g, t;
+    if (pred) {
+      load_opt(g, b.gpred_o, off, d, lane);
+      const float al = (float)a.pred_alpha;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        t.v[j] = make_float4(al * g.v[j].x, al * g.v[j].y, al * g.v[j].z, al * g.v[j].w);
+        g.v[j] = make_float4(one_minus_alpha * g.v[j].x, one_minus_alpha * g.v[j].y,
+                             one_minus_alpha * g.v[j].z, one_minus_alpha * g.v[j].w);
+      }
+      store_row(t, b.gpred + off, d, lane);
+      store_row(g, b.gM + off, d, lane);
+    } else {
+      zero_frag(g);
+      store_row(g, b.gM + off, d, lane);
+    }
+    load_opt(g, b.gnum_o, off, d, lane);
+    store_row(g, b.gnum + off, d, lane);
+    load_opt(g, b.gden_o, off, d, lane);
+    store_row(g, b.gden + off, d, lane);
+    if (afd) {
+      load_opt(g, b.gvar_o, off, d, lane);
+      store_row(g, b.gvar + off, d, lane);
+    }
+    if (rt && lane == 0) {
+      b.gradius[row] = b.gradius_o ? b.gradius_o[row] : 0.f;
+      b.gradius_var[row] = b.gradius_var_o ? b.gradius_var_o[row] : 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- o-projection backward
+template <int DCH, int RPW>
+__global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b) {
+  const ic_region_args& a = b.f;
+  const int r = blockIdx.y;
+  if (!region_has_work(a.mask, a.S, a.R, r)) return;
+  __shared__ float red[4][DCH * 256 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * (4 * RPW) + wave * RPW;
+  const size_t dd = (size_t)d * d;
+  const float* Wo = a.W + ((size_t)r * 4 + 3) * dd;
+  RowFrag<DCH> wo[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    if (row0 + i < d)
+      load_row(wo[i], Wo + (size_t)(row0 + i) * d, d, lane);
+    else
+      zero_frag(wo[i]);
+  }
+  const bool rt = a.flags & IC_F_RT;
+  const int SR = a.S * a.R;
+  for (int s = 0; s < a.S; ++s) {
+    const int row = s * a.R + r;
+    if (!a.mask[row]) continue;  // block-uniform
+    const size_t off = (size_t)row * d;
+    RowFrag<DCH> op, acc;
+    load_row(op, a.y + off, d, lane);
+    float scale = 1.0f;
+    if (rt) {
+      const float nrm = a.ynorm[row];
+      scale = a.radius_o[row];
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        op.v[j].x /= nrm; op.v[j].y /= nrm; op.v[j].z /= nrm; op.v[j].w /= nrm;
+      }
+    }
+    zero_frag(acc);
+    float part_rt = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int ch = row0 + i;
+      if (ch < d) {  // wave-uniform
+        const float g = b.ghpre[off + ch];
+        float gi = g;
+        if (rt) {
+          const float hd = wave_sum(dot_frag(wo[i], op));
+          part_rt += g * hd;
+          gi = scale * g;
+        }
+        if (lane == 0) b.tape_g[((size_t)row * 4 + 3) * d + ch] = gi;
+        axpy_frag(acc, gi, wo[i]);
+      }
+    }
+    // cross-wave reduction of the partial W_o^T g
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      float* p = &red[wave][256 * j + 4 * lane];
+      p[0] = acc.v[j].x; p[1] = acc.v[j].y; p[2] = acc.v[j].z; p[3] = acc.v[j].w;
+    }
+    if (lane == 0) red[wave][DCH * 256] = part_rt;
+    __syncthreads();
+    if (wave == 0) {
+      RowFrag<DCH> tot;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        const int c = 256 * j + 4 * lane;
+        tot.v[j].x = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        tot.v[j].y = (red[0][c + 1] + red[1][c + 1]) + (red[2][c + 1] + red[3][c + 1]);
+        tot.v[j].z = (red[0][c + 2] + red[1][c + 2]) + (red[2][c + 2] + red[3][c + 2]);
+        tot.v[j].w = (red[0][c + 3] + red[1][c + 3]) + (red[2][c + 3] + red[3][c + 3]);
+      }
+      store_row(tot, b.slab + ((size_t)blockIdx.x * SR + row) * d, d, lane);
+      if (rt && lane == 0) {
+        const int q = DCH * 256;
+        b.slab_rt[(size_t)blockIdx.x * SR + row] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+      }
+      if (blockIdx.x == 0) store_row(op, b.tape_o + off, d, lane);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- middle: gy + RT scalars
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_mid_bwd(ic_region_bwd_args b, int nslab) {
+  const ic_region_args& a = b.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const int SR = a.S * a.R;
+  if (row >= SR || !a.mask[row]) return;
+  const int d = a.d, r = row % a.R;
+  const size_t off = (size_t)row * d;
+  RowFrag<DCH> g, t;
+  zero_frag(g);
+  for (int sl = 0; sl < nslab; ++sl) {
+    load_row(t, b.slab + ((size_t)sl * SR + row) * d, d, lane);
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      g.v[j].x += t.v[j].x; g.v[j].y += t.v[j].y; g.v[j].z += t.v[j].z; g.v[j].w += t.v[j].w;
+    }
+  }
+  if (a.flags & IC_F_RT) {
+    // g currently holds d/d dir (already scaled by radius'); region.py:219-235
+    RowFrag<DCH> y;
+    load_row(y, a.y + off, d, lane);
+    float g_rho_h = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) g_rho_h += b.slab_rt[(size_t)sl * SR + row];
+    const float n = a.ynorm[row];
+    const float ynrm = sqrtf(wave_sum(dot_frag(y, y)));
+    const float gdy = wave_sum(dot_frag(g, y));
+    const float rho = a.radius[row];
+    const float pn_p = a.rpn_param[r], on_p = a.ron_param[r];
+    const float pv = a.radius_var[row] + ic_noise(pn_p);
+    const float on = ic_noise(on_p);
+    const float D = pv + on + IC_EPS_DIV;
+    const float gain = pv / D;
+    const float mu = (float)0.2;
+    const float Grho = (b.gradius_o ? b.gradius_o[row] : 0.f) + g_rho_h;
+    const float Grv = b.gradius_var_o ? b.gradius_var_o[row] : 0.f;
+    const float g_gain = Grho * mu * (n - rho) - Grv * pv;
+    const float g_pv = Grv * (1.0f - gain) + g_gain * (on + IC_EPS_DIV) / (D * D);
+    const float g_on = -g_gain * pv / (D * D);
+    float g_n = Grho * mu * gain - gdy / (n * n);
+    if (!(ynrm >= IC_EPS_DIV)) g_n = 0.f;  // clamp_min blocks the gradient
+    const float coef = ynrm > 0.f ? g_n / ynrm : 0.f;
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      g.v[j].x = g.v[j].x / n + coef * y.v[j].x; g.v[j].y = g.v[j].y / n + coef * y.v[j].y;
+      g.v[j].z = g.v[j].z / n + coef * y.v[j].z; g.v[j].w = g.v[j].w / n + coef * y.v[j].w;
+    }
+    if (lane == 0) {
+      b.gradius[row] = Grho * (1.0f - mu * gain);
+      b.gradius_var[row] = g_pv;
+      b.g_rnoise_rows[row * 2 + 0] = g_pv * ic_noise_grad(pn_p);
+      b.g_rnoise_rows[row * 2 + 1] = g_on * ic_noise_grad(on_p);
+    }
+  }
+  store_row(g, b.gy + off, d, lane);
+}
+
+// ---------------------------------------------------------------- r,k,v + state backward
+template <int DCH, int RPW>
+__global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
+  const ic_region_args& a = b.f;
+  const int r = blockIdx.y;
+  if (!region_has_work(a.mask, a.S, a.R, r)) return;
+  __shared__ float red[4][DCH * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * (4 * RPW) + wave * RPW;
+  const size_t dd = (size_t)d * d;
+  const float* Wr = a.W + (size_t)r * 4 * dd;
+  const float* Wk = Wr + dd;
+  const float* Wv = Wk + dd;
+  RowFrag<DCH> wr[RPW], wk[RPW], wv[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    if (row0 + i < d) {
+      load_row(wr[i], Wr + (size_t)(row0 + i) * d, d, lane);
+      load_row(wk[i], Wk + (size_t)(row0 + i) * d, d, lane);
+      load_row(wv[i], Wv + (size_t)(row0 + i) * d, d, lane);
+    } else {
+      zero_frag(wr[i]); zero_frag(wk[i]); zero_frag(wv[i]);
+    }
+  }
+  const bool afd = a.flags & IC_F_AFD, vec = a.flags & IC_F_NOISE_VEC;
+  const int SR = a.S * a.R;
+  for (int s = 0; s < a.S; ++s) {
+    const int row = s * a.R + r;
+    if (!a.mask[row]) continue;  // block-uniform
+    const size_t off = (size_t)row * d;
+    const float steps = (float)(a.dt[row] + 1);
+    RowFrag<DCH> acc;
+    zero_frag(acc);
+#pragma unroll
+    for (int p = 0; p < RPW / 2; ++p) {
+      const int chr = row0 + 2 * p + (lane & 1);
+      const bool valid = chr < d;      // pairs are valid or invalid together (d even)
+      const int ch = valid ? chr : 0;  // clamp loads
+      const size_t idx = off + ch;
+      // ---- recompute the forward for this channel
+      const float rd = a.raw_decay[(size_t)r * d + ch];
+      const float rate = -ic_softplus(rd);
+      const float ex = expf(rate * steps);
+      const float lam = fmaxf(ex, IC_EPS_DIV);
+      const float num_in = a.num[idx], den_in = a.den[idx];
+      const float numd = num_in * lam, dend = den_in * lam;
+      const float rr = a.r_s[idx], kk = a.k_s[idx], vv = a.v_s[idx];
+      const float w = expf(fminf(kk, IC_MAX_EXP));
+      const float gy = b.gy[idx];
+      const float gno = b.gnum_o ? b.gnum_o[idx] : 0.f;
+      const float gdo = b.gden_o ? b.gden_o[idx] : 0.f;
+      float g_r, g_v, g_w, g_numd, g_dend, g_lam, g_k_extra = 0.f, g_var_in = 0.f;
+      float g_pn_p = 0.f, g_on_p = 0.f;
+      if (afd) {
+        const float pn_p = vec ? a.pn_param[(size_t)r * d + ch] : a.pn_param[r];
+        const float on_p = vec ? a.on_param[(size_t)r * d + ch] : a.on_param[r];
+        const float pn = ic_noise(pn_p), on = ic_noise(on_p);
+        const float var_in = a.var[idx];
+        const float vard = var_in * (lam * lam) + pn * steps;
+        const float dpe = dend + IC_EPS_DIV;
+        const float prd = numd / dpe;
+        const float resid = w * vv - prd;
+        const float e = expf(fminf(-kk, IC_MAX_EXP));
+        const float obs = e * on + IC_EPS_DIV;
+        const float T = vard + obs;
+        const float graw = vard / T;
+        const float gain = fminf(fmaxf(graw, IC_EPS_DIV), 1.0f);
+        const float st = prd + gain * resid;
+        const float den_n = dend + w;
+        const float gvo = b.gvar_o ? b.gvar_o[idx] : 0.f;
+        g_r = gy * st;
+        const float g_st = gy * rr + gno * den_n;
+        const float g_den_n = gno * st + gdo;
+        g_dend = g_den_n;
+        g_w = g_den_n;
+        const float g_gain = g_st * resid - gvo * vard;
+        const float g_resid = g_st * gain;
+        float g_vard = gvo * (1.0f - gain);
+        const float g_graw = (graw >= IC_EPS_DIV && graw <= 1.0f) ? g_gain : 0.f;
+        g_vard += g_graw * obs / (T * T);
+        const float g_obs = -g_graw * vard / (T * T);
+        const float g_prd = g_st - g_resid;
+        g_w += g_resid * vv;
+        g_v = g_resid * w;
+        g_numd = g_prd / dpe;
+        g_dend += -g_prd * prd / dpe;
+        const float g_e = g_obs * on;
+        g_on_p = g_obs * e * ic_noise_grad(on_p);
+        g_k_extra = (-kk <= IC_MAX_EXP) ? -g_e * e : 0.f;
+        g_var_in = g_vard * (lam * lam);
+        g_lam = g_numd * num_in + g_dend * den_in + g_vard * var_in * 2.0f * lam;
+        g_pn_p = g_vard * steps * ic_noise_grad(pn_p);
+      } else {
+        const float num_n = numd + w * vv, den_n = dend + w;
+        const float dpe = den_n + IC_EPS_DIV;
+        const float q = num_n / dpe;
+        g_r = gy * q;
+        const float g_q = gy * rr;
+        g_numd = gno + g_q / dpe;
+        g_dend = gdo - g_q * q / dpe;
+        g_v = g_numd * w;
+        g_w = g_numd * vv + g_dend;
+        g_lam = g_numd * num_in + g_dend * den_in;
+      }
+      const float g_k = ((kk <= IC_MAX_EXP) ? g_w * w : 0.f) + g_k_extra;
+      const float g_rate = (ex >= IC_EPS_DIV) ? g_lam * lam * steps : 0.f;
+      const float g_rd = -g_rate * ic_softplus_grad(rd);
+      const float g_rpre = g_r * rr * (1.0f - rr);
+      // rotation backward (iron_rope.py:63-64)
+      float g_vraw = g_v;
+      const float g_vo = __shfl_xor(g_v, 1, 64);
+      if (ch < 2 * a.m_time) {
+        const float th = a.step_pos * a.W_time[ch >> 1];
+        const float c = cosf(th), sn = sinf(th);
+        g_vraw = (lane & 1) ? (-g_vo * sn + g_v * c) : (g_v * c + g_vo * sn);
+      }
+      if (valid && lane < 2) {
+        b.gnum[idx] = g_numd * lam;
+        b.gden[idx] = g_dend * lam;
+        if (afd) {
+          b.gvar[idx] = g_var_in;
+          b.g_pn_rows[idx] = g_pn_p;
+          b.g_on_rows[idx] = g_on_p;
+        }
+        b.g_raw_decay_rows[idx] = g_rd;
+        float* tg = b.tape_g + (size_t)row * 4 * d;
+        tg[ch] = g_rpre;
+        tg[d + ch] = g_k;
+        tg[2 * d + ch] = g_vraw;
+      }
+      // broadcast both channels of the pair and accumulate W^T g
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const float br = valid ? __shfl(g_rpre, q2, 64) : 0.f;
+        const float bk = valid ? __shfl(g_k, q2, 64) : 0.f;
+        const float bv = valid ? __shfl(g_vraw, q2, 64) : 0.f;
+        axpy_frag(acc, br, wr[2 * p + q2]);
+        axpy_frag(acc, bk, wk[2 * p + q2]);
+        axpy_frag(acc, bv, wv[2 * p + q2]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      float* p = &red[wave][256 * j + 4 * lane];
+      p[0] = acc.v[j].x; p[1] = acc.v[j].y; p[2] = acc.v[j].z; p[3] = acc.v[j].w;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      RowFrag<DCH> tot;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        const int c = 256 * j + 4 * lane;
+        tot.v[j].x = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        tot.v[j].y = (red[0][c + 1] + red[1][c + 1]) + (red[2][c + 1] + red[3][c + 1]);
+        tot.v[j].z = (red[0][c + 2] + red[1][c + 2]) + (red[2][c + 2] + red[3][c + 2]);
+        tot.v[j].w = (red[0][c + 3] + red[1][c + 3]) + (red[2][c + 3] + red[3][c + 3]);
+      }
+      store_row(tot, b.slab + ((size_t)blockIdx.x * SR + row) * d, d, lane);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- prologue backward
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_pro_bwd(ic_region_bwd_args b, int nslab) {
+  const ic_region_args& a = b.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const int SR = a.S * a.R;
+  if (row >= SR || !a.mask[row]) return;
+  const int d = a.d, r = row % a.R, s = row / a.R;
+  const size_t off = (size_t)row * d;
+  const float inv_d = 1.0f / (float)d;
+  RowFrag<DCH> g, t, u, w;
+  load_row(g, b.ghpre + off, d, lane);  // residual path h = x + ...
+  for (int sl = 0; sl < nslab; ++sl) {
+    load_row(t, b.slab + ((size_t)sl * SR + row) * d, d, lane);
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      g.v[j].x += t.v[j].x; g.v[j].y += t.v[j].y; g.v[j].z += t.v[j].z; g.v[j].w += t.v[j].w;
+    }
+  }
+  load_row(t, a.x + off, d, lane);
+  store_row(t, b.tape_x + off, d, lane);
+  // ---- region norm: x = nw * u1 * inv1
+  load_row(u, a.u1 + off, d, lane);
+  load_row(w, a.norm_w + (size_t)r * d, d, lane);
+  const float inv1 = a.inv_s[row * 2 + 1];
+  RowFrag<DCH> gw;
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    gw.v[j] = make_float4(g.v[j].x * u.v[j].x * inv1, g.v[j].y * u.v[j].y * inv1,
+                          g.v[j].z * u.v[j].z * inv1, g.v[j].w * u.v[j].w * inv1);
+    g.v[j] = make_float4(g.v[j].x * w.v[j].x, g.v[j].y * w.v[j].y, g.v[j].z * w.v[j].z,
+                         g.v[j].w * w.v[j].w);
+  }
+  store_row(gw, b.g_norm_w_rows + off, d, lane);
+  float dotp = wave_sum(dot_frag(g, u));
+  float k3 = dotp * inv1 * inv1 * inv1 * inv_d;
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    g.v[j] = make_float4(g.v[j].x * inv1 - u.v[j].x * k3, g.v[j].y * inv1 - u.v[j].y * k3,
+                         g.v[j].z * inv1 - u.v[j].z * k3, g.v[j].w * inv1 - u.v[j].w * k3);
+  }
+  if (a.flags & IC_F_PRED) store_row(g, b.gpred + off, d, lane);
+  if (a.flags & IC_F_NORM_IN) {
+    const bool io = a.sensor && (r == a.sensor_idx || r == a.motor_idx);
+    load_row(u, a.M + off, d, lane);
+    if (io) {
+      load_row(t, a.sensor + (size_t)s * d, d, lane);
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        u.v[j].x += t.v[j].x; u.v[j].y += t.v[j].y; u.v[j].z += t.v[j].z; u.v[j].w += t.v[j].w;
+      }
+    }
+    load_row(w, a.norm_in_w, d, lane);
+    const float inv0 = a.inv_s[row * 2 + 0];
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      gw.v[j] = make_float4(g.v[j].x * u.v[j].x * inv0, g.v[j].y * u.v[j].y * inv0,
+                            g.v[j].z * u.v[j].z * inv0, g.v[j].w * u.v[j].w * inv0);
+      g.v[j] = make_float4(g.v[j].x * w.v[j].x, g.v[j].y * w.v[j].y, g.v[j].z * w.v[j].z,
+                           g.v[j].w * w.v[j].w);
+    }
+    store_row(gw, b.g_norm_in_rows + off, d, lane);
+    dotp = wave_sum(dot_frag(g, u));
+    k3 = dotp * inv0 * inv0 * inv0 * inv_d;
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      g.v[j] = make_float4(g.v[j].x * inv0 - u.v[j].x * k3, g.v[j].y * inv0 - u.v[j].y * k3,
+                           g.v[j].z * inv0 - u.v[j].z * k3, g.v[j].w * inv0 - u.v[j].w * k3);
+    }
+    if (io && b.gsens) {
+      if (r == a.sensor_idx) store_row(g, b.gsens + ((size_t)s * 2 + 0) * d, d, lane);
+      else store_row(g, b.gsens + ((size_t)s * 2 + 1) * d, d, lane);
+    }
+  }
+  store_row(g, b.gM + off, d, lane);
+}
+
+// ---------------------------------------------------------------- deferred weight gradient
+// Block (row slice of 8, matrix j, region r): dW[r,j,rows,:] += sum_{t,s} g[t,s,r,j,rows] (x) op[t,s,r,:]
+template <int DCH>
+__global__ __launch_bounds__(256) void k_wgrad_region(ic_wgrad_region_args a) {
+  const int r = blockIdx.z, jm = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * 8 + wave * 2;
+  if (row0 >= d) return;
+  RowFrag<DCH> acc0, acc1, op;
+  zero_frag(acc0);
+  zero_frag(acc1);
+  const int SR = a.S * a.R;
+  bool any = false;
+  for (int t = 0; t < a.T; ++t) {
+    if (!a.visited[t]) continue;
+    for (int s = 0; s < a.S; ++s) {
+      const size_t row = (size_t)t * SR + (size_t)s * a.R + r;
+      if (!a.mask[row]) continue;
+      any = true;
+      const float* g = a.tape_g + (row * 4 + jm) * d;
+      const float g0 = g[row0], g1 = g[row0 + 1];
+      load_row(op, (jm < 3 ? a.tape_x : a.tape_o) + row * d, d, lane);
+      axpy_frag(acc0, g0, op);
+      axpy_frag(acc1, g1, op);
+    }
+  }
+  if (!any) return;
+  float* out = a.gW + (((size_t)r * 4 + jm) * d + row0) * d;
+  RowFrag<DCH> cur;
+  load_row(cur, out, d, lane);
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    cur.v[j].x += acc0.v[j].x; cur.v[j].y += acc0.v[j].y; cur.v[j].z += acc0.v[j].z; cur.v[j].w += acc0.v[j].w;
+  }
+  store_row(cur, out, d, lane);
+  load_row(cur, out + d, d, lane);
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    cur.v[j].x += acc1.v[j].x; cur.v[j].y += acc1.v[j].y; cur.v[j].z += acc1.v[j].z; cur.v[j].w += acc1.v[j].w;
+  }
+  store_row(cur, out + d, d, lane);
+  if (blockIdx.x == 0 && jm == 0 && threadIdx.x == 0) a.touched[r] = 1;
+}
+
+}  // namespace
+
+extern "C" int ic_bwd_nslab(int32_t d) { return d <= 256 ? ic_ceil_div(d, 32) : ic_ceil_div(d, 8); }
+
+extern "C" int ic_region_phase_bwd(const ic_region_bwd_args* b, ic_stream_t stream) {
+  IC_REQUIRE(b != nullptr, "ic_region_phase_bwd: NULL args");
+  const ic_region_args* a = &b->f;
+  IC_REQUIRE(a->S > 0 && a->R > 0, "ic_region_phase_bwd: S=%d R=%d", a->S, a->R);
+  IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "ic_region_phase_bwd: d=%d unsupported", a->d);
+  IC_REQUIRE(a->W && a->norm_w && a->raw_decay && a->M && a->mask && a->num && a->den && a->dt &&
+                 a->x && a->u1 && a->inv_s && a->r_s && a->k_s && a->v_s && a->y && a->hpre && a->gate,
+             "ic_region_phase_bwd: NULL forward pointer");
+  IC_REQUIRE(b->gM && b->gnum && b->gden && b->g_norm_w_rows && b->g_raw_decay_rows && b->tape_g &&
+                 b->tape_x && b->tape_o && b->ghpre && b->gy && b->slab,
+             "ic_region_phase_bwd: NULL gradient/workspace pointer");
+  IC_REQUIRE(!(a->flags & IC_F_PRED) || b->gpred, "ic_region_phase_bwd: gpred is NULL");
+  IC_REQUIRE(!(a->flags & IC_F_NORM_IN) || (a->norm_in_w && b->g_norm_in_rows),
+             "ic_region_phase_bwd: norm_in buffers are NULL");
+  IC_REQUIRE(!(a->flags & IC_F_AFD) || (a->var && a->pn_param && a->on_param && b->gvar &&
+                                        b->g_pn_rows && b->g_on_rows),
+             "ic_region_phase_bwd: AFD buffers are NULL");
+  IC_REQUIRE(!(a->flags & IC_F_RT) || (a->radius && a->radius_var && a->radius_o && a->ynorm &&
+                                       a->rpn_param && a->ron_param && b->gradius &&
+                                       b->gradius_var && b->g_rnoise_rows && b->slab_rt),
+             "ic_region_phase_bwd: radial-tangential buffers are NULL");
+  IC_REQUIRE(a->m_time == 0 || a->W_time, "ic_region_phase_bwd: W_time is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = a->S * a->R;
+  const int nslab = ic_bwd_nslab(a->d);
+  const dim3 blk(256), grow(ic_ceil_div(rows, 4)), gmat(nslab, a->R);
+  const float oma = (float)(1.0 - a->pred_alpha);
+  if (a->d <= 256) {
+    constexpr int DCH = 1;
+    hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma);
+    hipLaunchKernelGGL((k_region_out_bwd<DCH, 8>), gmat, blk, 0, st, *b);
+    hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 8>), gmat, blk, 0, st, *b);
+    hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+  } else if (a->d <= 512) {
+    constexpr int DCH = 2;
+    hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma);
+    hipLaunchKernelGGL((k_region_out_bwd<DCH, 2>), gmat, blk, 0, st, *b);
+    hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 2>), gmat, blk, 0, st, *b);
+    hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+  } else {
+    constexpr int DCH = 4;
+    hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma);
+    hipLaunchKernelGGL((k_region_out_bwd<DCH, 2>), gmat, blk, 0, st, *b);
+    hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 2>), gmat, blk, 0, st, *b);
+    hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+  }
+  IC_LAUNCH_CHECK("ic_region_phase_bwd");
+  return IC_OK;
+}
+
+extern "C" int ic_region_wgrad(const ic_wgrad_region_args* a, ic_stream_t stream) {
+  IC_REQUIRE(a != nullptr, "ic_region_wgrad: NULL args");
+  IC_REQUIRE(a->T >= 0 && a->S > 0 && a->R > 0, "ic_region_wgrad: T=%d S=%d R=%d", a->T, a->S, a->R);
+  IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "ic_region_wgrad: d=%d unsupported", a->d);
+  IC_REQUIRE(a->tape_g && a->tape_x && a->tape_o && a->mask && a->visited && a->gW && a->touched,
+             "ic_region_wgrad: NULL pointer");
+  if (a->T == 0) return IC_OK;
+  const dim3 grid(ic_ceil_div(a->d, 8), 4, a->R);
+  IC_DISPATCH_DCH(a->d, { hipLaunchKernelGGL(k_wgrad_region<DCH>, grid, dim3(256), 0, (hipStream_t)stream, *a); });
+  IC_LAUNCH_CHECK("ic_region_wgrad");
+  return IC_OK;
+}

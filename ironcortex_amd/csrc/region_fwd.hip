@@ -1,0 +1,410 @@
+// Region phase, forward: prologue -> rkv/state -> out -> finish.
+// Replaces the Python loop over regions in CortexReasoner.forward_inner_step
+// (reference model.py:271-294) and RWKVRegionCell.step/predict/skip (region.py:128-249).
+//
+// Parallelisation: the r/k/v/o GEMVs are weight-bandwidth bound (16 d^2 bytes per active
+// region, 0.5 flop/byte), so each workgroup owns a ROW SLICE of one region's matrices, keeps
+// it in registers, and serves every stream that has the region active.  A wave owns whole
+// rows (lane l holds columns 4l..4l+3 of each 256-column chunk => one 1 KiB coalesced
+// request per row per wave) and reduces dot products with wave64 xor-shuffles.
+#include "ic_common.h"
+
+namespace {
+
+constexpr int kRowsPerBlock = 8;  // 4 waves x one channel pair
+
+// ---------------------------------------------------------------- prologue (wave per row)
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_pro(ic_region_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  if (!a.mask[row]) return;
+  const int s = row / a.R, r = row % a.R;
+  const int d = a.d;
+  const float inv_d = 1.0f / (float)d;
+  RowFrag<DCH> u;
+  load_row(u, a.M + (size_t)row * d, d, lane);
+  float inv0 = 1.0f;
+  if (a.flags & IC_F_NORM_IN) {
+    if (a.sensor && (r == a.sensor_idx || r == a.motor_idx)) {
+      RowFrag<DCH> sv;
+      load_row(sv, a.sensor + (size_t)s * d, d, lane);
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        u.v[j].x += sv.v[j].x; u.v[j].y += sv.v[j].y; u.v[j].z += sv.v[j].z; u.v[j].w += sv.v[j].w;
+      }
+    }
+    float ss = wave_sum(dot_frag(u, u));
+    float s0 = sqrtf(ss * inv_d + IC_RMS_EPS);
+    inv0 = 1.0f / s0;
+    RowFrag<DCH> w;
+    load_row(w, a.norm_in_w, d, lane);
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      u.v[j].x = w.v[j].x * (u.v[j].x / s0); u.v[j].y = w.v[j].y * (u.v[j].y / s0);
+      u.v[j].z = w.v[j].z * (u.v[j].z / s0); u.v[j].w = w.v[j].w * (u.v[j].w / s0);
+    }
+  }
+  if (a.flags & IC_F_PRED) {
+    RowFrag<DCH> p;
+    load_row(p, a.pred + (size_t)row * d, d, lane);
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      u.v[j].x += p.v[j].x; u.v[j].y += p.v[j].y; u.v[j].z += p.v[j].z; u.v[j].w += p.v[j].w;
+    }
+  }
+  store_row(u, a.u1 + (size_t)row * d, d, lane);
+  float ss1 = wave_sum(dot_frag(u, u));
+  float s1 = sqrtf(ss1 * inv_d + IC_RMS_EPS);
+  RowFrag<DCH> w;
+  load_row(w, a.norm_w + (size_t)r * d, d, lane);
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    u.v[j].x = w.v[j].x * (u.v[j].x / s1); u.v[j].y = w.v[j].y * (u.v[j].y / s1);
+    u.v[j].z = w.v[j].z * (u.v[j].z / s1); u.v[j].w = w.v[j].w * (u.v[j].w / s1);
+  }
+  store_row(u, a.x + (size_t)row * d, d, lane);
+  if (lane == 0) {
+    a.inv_s[row * 2 + 0] = inv0;
+    a.inv_s[row * 2 + 1] = 1.0f / s1;
+  }
+}
+
+__device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int R, int r) {
+  for (int s = 0; s < S; ++s)
+    if (mask[s * R + r]) return true;
+  return false;
+}
+
+// ---------------------------------------------------------------- r,k,v GEMVs + state update
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
+  const int r = blockIdx.y;
+  if (!region_has_work(a.mask, a.S, a.R, r)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;  // even: a rotation pair
+  if (row0 >= d) return;
+  const size_t dd = (size_t)d * d;
+  const float* Wr = a.W + (size_t)r * 4 * dd;
+  const float* Wk = Wr + dd;
+  const float* Wv = Wk + dd;
+  RowFrag<DCH> wr[2], wk[2], wv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    load_row(wr[i], Wr + (size_t)(row0 + i) * d, d, lane);
+    load_row(wk[i], Wk + (size_t)(row0 + i) * d, d, lane);
+    load_row(wv[i], Wv + (size_t)(row0 + i) * d, d, lane);
+  }
+  const bool afd = a.flags & IC_F_AFD;
+  const int ch = row0 + (lane & 1);  // lanes 0/1 finish one channel each
+  // per-channel constants
+  const float rate = -ic_softplus(a.raw_decay[(size_t)r * d + ch]);  // region.py:94-95
+  float pn = 0.f, on = 0.f;
+  if (afd) {
+    const bool vec = a.flags & IC_F_NOISE_VEC;
+    pn = ic_noise(vec ? a.pn_param[(size_t)r * d + ch] : a.pn_param[r]);
+    on = ic_noise(vec ? a.on_param[(size_t)r * d + ch] : a.on_param[r]);
+  }
+  float rc = 1.f, rs = 0.f;
+  const bool rot = ch < 2 * a.m_time;
+  if (rot) {
+    float th = a.step_pos * a.W_time[ch >> 1];  // region.py:186
+    rc = cosf(th);
+    rs = sinf(th);
+  }
+  for (int s = 0; s < a.S; ++s) {
+    const int row = s * a.R + r;
+    if (!a.mask[row]) continue;
+    RowFrag<DCH> xv;
+    load_row(xv, a.x + (size_t)row * d, d, lane);
+    float pr0 = wave_sum(dot_frag(wr[0], xv)), pr1 = wave_sum(dot_frag(wr[1], xv));
+    float pk0 = wave_sum(dot_frag(wk[0], xv)), pk1 = wave_sum(dot_frag(wk[1], xv));
+    float pv0 = wave_sum(dot_frag(wv[0], xv)), pv1 = wave_sum(dot_frag(wv[1], xv));
+    if (lane < 2) {
+      const size_t idx = (size_t)row * d + ch;
+      const float rr = ic_sigmoid(lane ? pr1 : pr0);
+      const float kk = lane ? pk1 : pk0;
+      float vv = lane ? pv1 : pv0;
+      if (rot) vv = lane ? (pv0 * rs + pv1 * rc) : (pv0 * rc - pv1 * rs);  // iron_rope.py:63-64
+      const float steps = (float)(a.dt[row] + 1);
+      const float lam = fmaxf(expf(rate * steps), IC_EPS_DIV);  // region.py:97-98
+      const float numd = a.num[idx] * lam, dend = a.den[idx] * lam;  // region.py:131-133
+      const float w = expf(fminf(kk, IC_MAX_EXP));  // region.py:190
+      float yv, num_n, den_n;
+      if (afd) {  // region.py:192-212
+        const float vard = a.var[idx] * (lam * lam) + pn * steps;  // region.py:135
+        const float prd = numd / (dend + IC_EPS_DIV);
+        const float resid = w * vv - prd;
+        const float obs = expf(fminf(-kk, IC_MAX_EXP)) * on + IC_EPS_DIV;
+        float gain = vard / (vard + obs);
+        gain = fminf(fmaxf(gain, IC_EPS_DIV), 1.0f);  // fp32(1 - 1e-8) == 1
+        const float st = prd + gain * resid;
+        den_n = dend + w;
+        num_n = st * den_n;
+        a.var_o[idx] = (1.0f - gain) * vard;
+        a.sterm[idx] = (resid * resid) * (1.0f / (vard + obs));
+        yv = rr * st;
+      } else {  // region.py:214-216
+        num_n = numd + w * vv;
+        den_n = dend + w;
+        yv = rr * (num_n / (den_n + IC_EPS_DIV));
+      }
+      a.num_o[idx] = num_n;
+      a.den_o[idx] = den_n;
+      a.y[idx] = yv;
+      a.r_s[idx] = rr;
+      a.k_s[idx] = kk;
+      a.v_s[idx] = vv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- output projection (+ radial/tangential)
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_out(ic_region_args a) {
+  const int r = blockIdx.y;
+  if (!region_has_work(a.mask, a.S, a.R, r)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
+  if (row0 >= d) return;
+  const size_t dd = (size_t)d * d;
+  const float* Wo = a.W + ((size_t)r * 4 + 3) * dd;
+  RowFrag<DCH> wo[2];
+  load_row(wo[0], Wo + (size_t)row0 * d, d, lane);
+  load_row(wo[1], Wo + (size_t)(row0 + 1) * d, d, lane);
+  const bool rt = a.flags & IC_F_RT;
+  const int ch = row0 + (lane & 1);
+  for (int s = 0; s < a.S; ++s) {
+    const int row = s * a.R + r;
+    if (!a.mask[row]) continue;
+    RowFrag<DCH> yv;
+    load_row(yv, a.y + (size_t)row * d, d, lane);
+    float scale = 1.0f;
+    if (rt) {  // region.py:219-235
+      const float nrm = fmaxf(sqrtf(wave_sum(dot_frag(yv, yv))), IC_EPS_DIV);
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        yv.v[j].x /= nrm; yv.v[j].y /= nrm; yv.v[j].z /= nrm; yv.v[j].w /= nrm;
+      }
+      const float rad = a.radius[row];
+      const float pvar = a.radius_var[row] + ic_noise(a.rpn_param[r]);
+      const float resid = nrm - rad;
+      const float gain = pvar / (pvar + ic_noise(a.ron_param[r]) + IC_EPS_DIV);
+      const float upd = rad + gain * resid;
+      const float mu = (float)0.2, omu = (float)(1.0 - 0.2);
+      scale = omu * rad + mu * upd;
+      if (blockIdx.x == 0 && wave == 0) {
+        if (a.last_dir) store_row(yv, a.last_dir + (size_t)row * d, d, lane);
+        if (lane == 0) {
+          a.radius_o[row] = scale;
+          a.radius_var_o[row] = (1.0f - gain) * pvar;
+          a.ynorm[row] = nrm;
+          if (a.last_norm) a.last_norm[row] = nrm;
+        }
+      }
+    }
+    float h0 = wave_sum(dot_frag(wo[0], yv)), h1 = wave_sum(dot_frag(wo[1], yv));
+    if (lane < 2) {
+      const size_t idx = (size_t)row * d + ch;
+      const float hd = lane ? h1 : h0;
+      a.hpre[idx] = a.x[idx] + (rt ? scale * hd : hd);
+    }
+  }
+}
+
+}  // namespace
+
+// k-th largest |x| over a wave-distributed row, as raw float bits (utils.py:53).
+// Padding lanes must hold 0.  Bit-by-bit search: largest t with count(|x| >= t) >= k.
+template <int DCH>
+__device__ __forceinline__ float kth_largest_abs(const RowFrag<DCH>& h, int k) {
+  uint32_t u[4 * DCH];
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    u[4 * j + 0] = __float_as_uint(fabsf(h.v[j].x));
+    u[4 * j + 1] = __float_as_uint(fabsf(h.v[j].y));
+    u[4 * j + 2] = __float_as_uint(fabsf(h.v[j].z));
+    u[4 * j + 3] = __float_as_uint(fabsf(h.v[j].w));
+  }
+  uint32_t t = 0;
+  for (int b = 30; b >= 0; --b) {
+    const uint32_t trial = t | (1u << b);
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 4 * DCH; ++e) cnt += __popcll(__ballot(u[e] >= trial));
+    if (cnt >= k) t = trial;
+  }
+  return __uint_as_float(t);
+}
+
+__device__ __forceinline__ float kwta_gate(float v, float thr, bool soft, float temp) {
+  const float av = fabsf(v);
+  if (av >= thr) return 1.0f;
+  return soft ? ic_sigmoid((av - thr) / temp) : 0.0f;  // utils.py:55-57
+}
+
+template <int DCH>
+__device__ __forceinline__ void kwta_row(const RowFrag<DCH>& h, RowFrag<DCH>& out, RowFrag<DCH>& g,
+                                         int d, int k, bool soft, float temp) {
+  if (k <= 0) {  // utils.py:48-49
+    zero_frag(out);
+    zero_frag(g);
+    return;
+  }
+  k = min(max(k, 1), d);
+  const float thr = kth_largest_abs(h, k);
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    g.v[j].x = kwta_gate(h.v[j].x, thr, soft, temp); g.v[j].y = kwta_gate(h.v[j].y, thr, soft, temp);
+    g.v[j].z = kwta_gate(h.v[j].z, thr, soft, temp); g.v[j].w = kwta_gate(h.v[j].w, thr, soft, temp);
+    out.v[j].x = h.v[j].x * g.v[j].x; out.v[j].y = h.v[j].y * g.v[j].y;
+    out.v[j].z = h.v[j].z * g.v[j].z; out.v[j].w = h.v[j].w * g.v[j].w;
+  }
+}
+
+namespace {
+
+// ---------------------------------------------------------------- finish (wave per row)
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_fin(ic_region_args a, float one_minus_alpha) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  const int d = a.d;
+  const size_t off = (size_t)row * d;
+  const bool afd = a.flags & IC_F_AFD, rt = a.flags & IC_F_RT, pred = a.flags & IC_F_PRED;
+  RowFrag<DCH> z;
+  zero_frag(z);
+  if (a.mask[row]) {
+    RowFrag<DCH> h, out, g;
+    load_row(h, a.hpre + off, d, lane);
+    if (a.flags & IC_F_NOKWTA) {
+      out = h;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) g.v[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+    } else {
+      kwta_row(h, out, g, d, a.kwta_k, (a.flags & IC_F_KWTA_SOFT) != 0, a.kwta_temp);
+    }
+    store_row(out, a.H + off, d, lane);
+    store_row(g, a.gate + off, d, lane);
+    if (pred) store_row(z, a.pred_o + off, d, lane);  // region.py:175
+    if (afd) {                                         // region.py:207-211
+      RowFrag<DCH> st;
+      load_row(st, a.sterm + off, d, lane);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) sum += (st.v[j].x + st.v[j].y) + (st.v[j].z + st.v[j].w);
+      sum = wave_sum(sum);
+      if (lane == 0)
+        a.surprise_o[row] = (float)0.99 * a.surprise[row] + (float)(1.0 - 0.99) * sum;
+    }
+    if (lane == 0) a.dt_o[row] = 0;  // region.py:179
+  } else {
+    store_row(z, a.H + off, d, lane);  // model.py:275
+    RowFrag<DCH> t;
+    if (pred) {  // region.py:146
+      RowFrag<DCH> p, m;
+      load_row(p, a.pred + off, d, lane);
+      load_row(m, a.M + off, d, lane);
+      const float al = (float)a.pred_alpha;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        t.v[j].x = al * p.v[j].x + one_minus_alpha * m.v[j].x;
+        t.v[j].y = al * p.v[j].y + one_minus_alpha * m.v[j].y;
+        t.v[j].z = al * p.v[j].z + one_minus_alpha * m.v[j].z;
+        t.v[j].w = al * p.v[j].w + one_minus_alpha * m.v[j].w;
+      }
+      store_row(t, a.pred_o + off, d, lane);
+    }
+    load_row(t, a.num + off, d, lane);
+    store_row(t, a.num_o + off, d, lane);
+    load_row(t, a.den + off, d, lane);
+    store_row(t, a.den_o + off, d, lane);
+    if (afd) {
+      load_row(t, a.var + off, d, lane);
+      store_row(t, a.var_o + off, d, lane);
+    }
+    if (lane == 0) {
+      a.dt_o[row] = a.dt[row] + 1;  // region.py:137-138
+      if (afd) a.surprise_o[row] = a.surprise[row];
+      if (rt) {
+        a.radius_o[row] = a.radius[row];
+        a.radius_var_o[row] = a.radius_var[row];
+      }
+    }
+  }
+}
+
+template <int DCH>
+__global__ __launch_bounds__(256) void k_kwta_rows(const float* x, float* y, float* gate, int rows,
+                                                   int d, int k, int soft, float temp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  RowFrag<DCH> h, out, g;
+  load_row(h, x + (size_t)row * d, d, lane);
+  kwta_row(h, out, g, d, k, soft != 0, temp);
+  store_row(out, y + (size_t)row * d, d, lane);
+  if (gate) store_row(g, gate + (size_t)row * d, d, lane);
+}
+
+}  // namespace
+
+static int check_region_args(const ic_region_args* a, const char* who) {
+  IC_REQUIRE(a != nullptr, "%s: NULL args", who);
+  IC_REQUIRE(a->S > 0 && a->R > 0, "%s: S=%d R=%d must be positive", who, a->S, a->R);
+  IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024,
+             "%s: d=%d unsupported (need multiple of 4 in [4,1024])", who, a->d);
+  IC_REQUIRE(a->m_time >= 0 && 2 * a->m_time <= a->d, "%s: m_time=%d out of range", who, a->m_time);
+  IC_REQUIRE(a->W && a->norm_w && a->raw_decay && a->M && a->mask && a->num && a->den && a->dt,
+             "%s: NULL parameter/input pointer", who);
+  IC_REQUIRE(a->m_time == 0 || a->W_time, "%s: W_time is NULL with m_time=%d", who, a->m_time);
+  IC_REQUIRE(!(a->flags & IC_F_NORM_IN) || a->norm_in_w, "%s: norm_in_w is NULL", who);
+  IC_REQUIRE(!(a->flags & IC_F_PRED) || (a->pred && a->pred_o), "%s: pred buffers are NULL", who);
+  IC_REQUIRE(!(a->flags & IC_F_AFD) || (a->var && a->var_o && a->pn_param && a->on_param &&
+                                        a->surprise && a->surprise_o && a->sterm),
+             "%s: AFD buffers are NULL", who);
+  IC_REQUIRE(!(a->flags & IC_F_RT) || (a->radius && a->radius_var && a->radius_o &&
+                                       a->radius_var_o && a->rpn_param && a->ron_param && a->ynorm),
+             "%s: radial-tangential buffers are NULL", who);
+  IC_REQUIRE(a->x && a->u1 && a->inv_s && a->r_s && a->k_s && a->v_s && a->y && a->hpre && a->gate,
+             "%s: NULL workspace pointer", who);
+  return IC_OK;
+}
+
+extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) {
+  int rc = check_region_args(a, "ic_region_phase_fwd");
+  if (rc) return rc;
+  IC_REQUIRE(a->H && a->num_o && a->den_o && a->dt_o, "ic_region_phase_fwd: NULL output pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = a->S * a->R;
+  const dim3 blk(256);
+  const dim3 grow(ic_ceil_div(rows, 4));
+  const dim3 gmat(ic_ceil_div(a->d, kRowsPerBlock), a->R);
+  const float oma = (float)(1.0 - a->pred_alpha);
+  IC_DISPATCH_DCH(a->d, {
+    hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a);
+    hipLaunchKernelGGL(k_region_rkv<DCH>, gmat, blk, 0, st, *a);
+    hipLaunchKernelGGL(k_region_out<DCH>, gmat, blk, 0, st, *a);
+    hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma);
+  });
+  IC_LAUNCH_CHECK("ic_region_phase_fwd");
+  return IC_OK;
+}
+
+extern "C" int ic_kwta_fwd(const float* x, float* y, float* gate, int32_t rows, int32_t d, int32_t k,
+                           int32_t soft, float temp, ic_stream_t stream) {
+  IC_REQUIRE(x && y, "ic_kwta_fwd: NULL pointer");
+  IC_REQUIRE(rows >= 0, "ic_kwta_fwd: rows=%d", rows);
+  IC_REQUIRE(d >= 4 && d % 4 == 0 && d <= 1024, "ic_kwta_fwd: d=%d unsupported", d);
+  if (rows == 0) return IC_OK;
+  IC_DISPATCH_DCH(d, {
+    hipLaunchKernelGGL(k_kwta_rows<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, gate, rows, d, k, soft, temp);
+  });
+  IC_LAUNCH_CHECK("ic_kwta_fwd");
+  return IC_OK;
+}

@@ -1,0 +1,589 @@
+// Hex-neighbour message routing (reference gate.py:251-335), forward + backward.
+//
+// Edge weights are read IN PLACE from the [nW,d,d] arena through widx[e]; the reference
+// torch.stack()s a fresh copy of every active edge matrix on each call (gate.py:272).
+// Default path: one launch, workgroup = (row slice, destination region), incoming edges are
+// walked in the reference's index_add_ order.  Precision-routed path: edge GEMVs (messages,
+// keys, queries) then a wave-per-destination softmax combine.
+#include "ic_common.h"
+
+namespace {
+
+constexpr int kRowsPerBlock = 8;
+
+// ---------------------------------------------------------------- default forward
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_fwd(ic_router_args a) {
+  const int r = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
+  if (row0 >= d) return;
+  const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
+  const size_t dd = (size_t)d * d;
+  for (int s = 0; s < a.S; ++s) {
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int src = a.src[e];
+      if (!a.mask_prev[s * a.R + src]) continue;
+      const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
+      RowFrag<DCH> w0, w1, h;
+      load_row(w0, W, d, lane);
+      load_row(w1, W + d, d, lane);
+      load_row(h, a.H + ((size_t)s * a.R + src) * d, d, lane);
+      const float m0 = wave_sum(dot_frag(w0, h)), m1 = wave_sum(dot_frag(w1, h));
+      const float bias = a.ebias[e];
+      acc0 += m0 * bias;  // gate.py:290,324 (w == 1)
+      acc1 += m1 * bias;
+    }
+    if (lane < 2) a.M[((size_t)s * a.R + r) * d + row0 + lane] = lane ? acc1 : acc0;
+  }
+}
+
+// ---------------------------------------------------------------- precision: edge GEMVs
+// blockIdx.y < E: message + key of edge e;  blockIdx.y >= E: query of region y-E.
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
+  if (row0 >= d) return;
+  const size_t dd = (size_t)d * d;
+  const int y = blockIdx.y;
+  if (y < a.E) {
+    const int e = y, src = a.src[e];
+    bool any = false;
+    for (int s = 0; s < a.S; ++s) any |= a.mask_prev[s * a.R + src] != 0;
+    if (!any) return;
+    const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
+    const float* K = a.key_W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
+    RowFrag<DCH> w0, w1, k0, k1, h;
+    load_row(w0, W, d, lane);
+    load_row(w1, W + d, d, lane);
+    load_row(k0, K, d, lane);
+    load_row(k1, K + d, d, lane);
+    const float bias = a.ebias[e];
+    for (int s = 0; s < a.S; ++s) {
+      if (!a.mask_prev[s * a.R + src]) continue;
+      load_row(h, a.H + ((size_t)s * a.R + src) * d, d, lane);
+      const float m0 = wave_sum(dot_frag(w0, h)), m1 = wave_sum(dot_frag(w1, h));
+      const float q0 = wave_sum(dot_frag(k0, h)), q1 = wave_sum(dot_frag(k1, h));
+      if (lane < 2) {
+        const size_t idx = ((size_t)s * a.E + e) * d + row0 + lane;
+        a.msg[idx] = (lane ? m1 : m0) * bias;
+        a.keyv[idx] = lane ? q1 : q0;
+      }
+    }
+  } else {
+    const int r = y - a.E;
+    const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
+    const float* Q = a.query_W + (size_t)r * dd + (size_t)row0 * d;
+    RowFrag<DCH> q0, q1, h;
+    bool loaded = false;
+    for (int s = 0; s < a.S; ++s) {
+      bool any = false;
+      for (int e = e0; e < e1; ++e) any |= a.mask_prev[s * a.R + a.src[e]] != 0;
+      if (!any) continue;
+      if (!loaded) {
+        load_row(q0, Q, d, lane);
+        load_row(q1, Q + d, d, lane);
+        loaded = true;
+      }
+      load_row(h, a.H + ((size_t)s * a.R + r) * d, d, lane);
+      const float v0 = wave_sum(dot_frag(q0, h)), v1 = wave_sum(dot_frag(q1, h));
+      if (lane < 2) a.q[((size_t)s * a.R + r) * d + row0 + lane] = lane ? v1 : v0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- precision: combine (wave per (s,dst))
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_combine(ic_router_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  const int d = a.d, s = row / a.R, r = row % a.R;
+  const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
+  const float sqrt_d = sqrtf((float)d);
+  RowFrag<DCH> hd, q, m, k, P, acc;
+  zero_frag(acc);
+  float logw[8];  // hex degree <= 6; checked on the host
+  float mx = -INFINITY;
+  bool any = false;
+  for (int e = e0; e < e1; ++e) {
+    const int i = e - e0;
+    logw[i] = -INFINITY;
+    if (!a.mask_prev[s * a.R + a.src[e]]) continue;
+    if (!any) {
+      load_row(hd, a.H + (size_t)row * d, d, lane);
+      load_row(q, a.q + (size_t)row * d, d, lane);
+      any = true;
+    }
+    const size_t eo = ((size_t)s * a.E + e) * d;
+    load_row(m, a.msg + eo, d, lane);
+    load_row(k, a.keyv + eo, d, lane);
+    load_row(P, a.raw_P + (size_t)a.widx[e] * d, d, lane);
+    const float score = wave_sum(dot_frag(q, k)) / sqrt_d;  // gate.py:308
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      const int c = 4 * lane + 256 * j;
+      if (c < d) {
+        float t;
+        t = m.v[j].x - hd.v[j].x; part += (t * t) * ic_softplus(P.v[j].x);
+        t = m.v[j].y - hd.v[j].y; part += (t * t) * ic_softplus(P.v[j].y);
+        t = m.v[j].z - hd.v[j].z; part += (t * t) * ic_softplus(P.v[j].z);
+        t = m.v[j].w - hd.v[j].w; part += (t * t) * ic_softplus(P.v[j].w);
+      }
+    }
+    const float mah = fminf(wave_sum(part), IC_MAX_EXP / 0.5f);  // gate.py:310
+    logw[i] = score - 0.5f * mah;
+    mx = fmaxf(mx, logw[i]);
+  }
+  if (any) {
+    float esum = 0.f;
+    for (int e = e0; e < e1; ++e)
+      if (logw[e - e0] != -INFINITY) esum += expf(logw[e - e0] - mx);
+    const float logZ = mx + logf(fmaxf(esum, IC_EPS_DIV));  // gate.py:316
+    for (int e = e0; e < e1; ++e) {
+      const int i = e - e0;
+      float w = 0.f;
+      if (logw[i] != -INFINITY) {
+        w = expf(logw[i] - logZ);
+        load_row(m, a.msg + ((size_t)s * a.E + e) * d, d, lane);
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          acc.v[j].x += w * m.v[j].x; acc.v[j].y += w * m.v[j].y;
+          acc.v[j].z += w * m.v[j].z; acc.v[j].w += w * m.v[j].w;
+        }
+      }
+      if (lane == 0) a.wgt[(size_t)s * a.E + e] = w;
+    }
+  } else if (lane == 0) {
+    for (int e = e0; e < e1; ++e) a.wgt[(size_t)s * a.E + e] = 0.f;
+  }
+  store_row(acc, a.M + (size_t)row * d, d, lane);
+}
+
+// ---------------------------------------------------------------- backward: per-destination stage
+// Produces, for every active edge, the gradient w.r.t. the biased message (tape_gmsg), and in
+// precision mode the key/query gradients and the direct d/dH_dst term.
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
+  const ic_router_args& a = b.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  const int d = a.d, s = row / a.R, r = row % a.R;
+  const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
+  const bool prec = a.flags & IC_RF_PRECISION;
+  RowFrag<DCH> G, t;
+  load_row(G, b.gM + (size_t)row * d, d, lane);
+  load_row(t, a.H + (size_t)row * d, d, lane);
+  store_row(t, b.tape_H + (size_t)row * d, d, lane);
+  bool any = false;
+  for (int e = e0; e < e1; ++e) {
+    const bool act = a.mask_prev[s * a.R + a.src[e]] != 0;
+    any |= act;
+    if (lane == 0) b.tape_eact[(size_t)s * a.E + e] = act ? 1 : 0;
+    if (act && !prec) store_row(G, b.tape_gmsg + ((size_t)s * a.E + e) * d, d, lane);
+  }
+  if (!prec) return;
+  if (lane == 0) b.tape_qact[row] = any ? 1 : 0;
+  RowFrag<DCH> gHd, gq;
+  zero_frag(gHd);
+  zero_frag(gq);
+  if (any) {
+    RowFrag<DCH> hd = t, q, m, k, P;
+    load_row(q, a.q + (size_t)row * d, d, lane);
+    const float sqrt_d = sqrtf((float)d);
+    // pass 1: g_w and the softmax inner product
+    float gw[8], inner = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int i = e - e0;
+      gw[i] = 0.f;
+      const float w = a.wgt[(size_t)s * a.E + e];
+      if (!a.mask_prev[s * a.R + a.src[e]]) continue;
+      load_row(m, a.msg + ((size_t)s * a.E + e) * d, d, lane);
+      gw[i] = wave_sum(dot_frag(G, m));
+      inner += w * gw[i];
+    }
+    for (int e = e0; e < e1; ++e) {
+      const int i = e - e0;
+      if (!a.mask_prev[s * a.R + a.src[e]]) continue;
+      const size_t eo = ((size_t)s * a.E + e) * d;
+      const float w = a.wgt[(size_t)s * a.E + e];
+      const float g_lw = w * (gw[i] - inner);
+      load_row(m, a.msg + eo, d, lane);
+      load_row(k, a.keyv + eo, d, lane);
+      load_row(P, a.raw_P + (size_t)a.widx[e] * d, d, lane);
+      // recompute the un-clamped mahalanobis term
+      float part = 0.f;
+      RowFrag<DCH> res, sp;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        res.v[j] = make_float4(m.v[j].x - hd.v[j].x, m.v[j].y - hd.v[j].y, m.v[j].z - hd.v[j].z,
+                               m.v[j].w - hd.v[j].w);
+        sp.v[j] = make_float4(ic_softplus(P.v[j].x), ic_softplus(P.v[j].y), ic_softplus(P.v[j].z),
+                              ic_softplus(P.v[j].w));
+        const int c = 4 * lane + 256 * j;
+        if (c < d)
+          part += (res.v[j].x * res.v[j].x) * sp.v[j].x + (res.v[j].y * res.v[j].y) * sp.v[j].y +
+                  (res.v[j].z * res.v[j].z) * sp.v[j].z + (res.v[j].w * res.v[j].w) * sp.v[j].w;
+      }
+      const float mahraw = wave_sum(part);
+      const float g_mah = (mahraw <= IC_MAX_EXP / 0.5f) ? -0.5f * g_lw : 0.f;
+      const float g_sc = g_lw / sqrt_d;
+      RowFrag<DCH> gm, gk, gP;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        float4 gr = make_float4(g_mah * 2.f * res.v[j].x * sp.v[j].x, g_mah * 2.f * res.v[j].y * sp.v[j].y,
+                                g_mah * 2.f * res.v[j].z * sp.v[j].z, g_mah * 2.f * res.v[j].w * sp.v[j].w);
+        gm.v[j] = make_float4(w * G.v[j].x + gr.x, w * G.v[j].y + gr.y, w * G.v[j].z + gr.z,
+                              w * G.v[j].w + gr.w);
+        gHd.v[j].x -= gr.x; gHd.v[j].y -= gr.y; gHd.v[j].z -= gr.z; gHd.v[j].w -= gr.w;
+        gk.v[j] = make_float4(g_sc * q.v[j].x, g_sc * q.v[j].y, g_sc * q.v[j].z, g_sc * q.v[j].w);
+        gq.v[j].x += g_sc * k.v[j].x; gq.v[j].y += g_sc * k.v[j].y;
+        gq.v[j].z += g_sc * k.v[j].z; gq.v[j].w += g_sc * k.v[j].w;
+        gP.v[j] = make_float4(g_mah * res.v[j].x * res.v[j].x * ic_softplus_grad(P.v[j].x),
+                              g_mah * res.v[j].y * res.v[j].y * ic_softplus_grad(P.v[j].y),
+                              g_mah * res.v[j].z * res.v[j].z * ic_softplus_grad(P.v[j].z),
+                              g_mah * res.v[j].w * res.v[j].w * ic_softplus_grad(P.v[j].w));
+      }
+      store_row(gm, b.tape_gmsg + eo, d, lane);
+      store_row(gk, b.tape_gkey + eo, d, lane);
+      store_row(gP, b.g_rawP_rows + eo, d, lane);
+    }
+  }
+  store_row(gHd, b.gHd + (size_t)row * d, d, lane);
+  store_row(gq, b.tape_gq + (size_t)row * d, d, lane);
+}
+
+// ---------------------------------------------------------------- backward: transposed GEMVs
+// blockIdx.y < E: W_e^T (ebias*gmsg) + Key_e^T gkey -> slab;  >= E: Q_r^T gq -> slab_q.
+template <int DCH, int RPW>
+__global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
+  const ic_router_args& a = b.f;
+  __shared__ float red[4][DCH * 256 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * (4 * RPW) + wave * RPW;
+  const size_t dd = (size_t)d * d;
+  const bool prec = a.flags & IC_RF_PRECISION;
+  const int y = blockIdx.y;
+  const bool is_q = y >= a.E;
+  const int e = y, r = y - a.E;
+  const int src = is_q ? r : a.src[e];
+  // block-uniform activity test
+  bool any = false;
+  for (int s = 0; s < a.S; ++s)
+    any |= is_q ? (b.tape_qact[s * a.R + r] != 0) : (a.mask_prev[s * a.R + src] != 0);
+  if (!any) return;
+  const float* W = is_q ? a.query_W + (size_t)r * dd : a.W + (size_t)a.widx[e] * dd;
+  const float* K = (!is_q && prec) ? a.key_W + (size_t)a.widx[e] * dd : nullptr;
+  RowFrag<DCH> w[RPW], kf[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    if (row0 + i < d) {
+      load_row(w[i], W + (size_t)(row0 + i) * d, d, lane);
+      if (K) load_row(kf[i], K + (size_t)(row0 + i) * d, d, lane);
+      else zero_frag(kf[i]);
+    } else {
+      zero_frag(w[i]);
+      zero_frag(kf[i]);
+    }
+  }
+  const float bias = is_q ? 1.0f : a.ebias[e];
+  const int SE = a.S * a.E, SR = a.S * a.R;
+  for (int s = 0; s < a.S; ++s) {
+    const bool act = is_q ? (b.tape_qact[s * a.R + r] != 0) : (a.mask_prev[s * a.R + src] != 0);
+    if (!act) continue;  // block-uniform
+    RowFrag<DCH> h, acc;
+    zero_frag(acc);
+    float part_b = 0.f;
+    float* gvec = is_q ? b.tape_gq + ((size_t)s * a.R + r) * d : b.tape_gmsg + ((size_t)s * a.E + e) * d;
+    const float* gkey = K ? b.tape_gkey + ((size_t)s * a.E + e) * d : nullptr;
+    if (!is_q) load_row(h, a.H + ((size_t)s * a.R + src) * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int ch = row0 + i;
+      if (ch < d) {  // wave-uniform
+        const float g = gvec[ch];
+        float gi = g;
+        if (!is_q) {
+          const float raw = wave_sum(dot_frag(w[i], h));
+          part_b += g * raw;  // d/d ebias
+          gi = g * bias;
+          if (lane == 0) gvec[ch] = gi;  // fold ebias into the tape entry
+        }
+        axpy_frag(acc, gi, w[i]);
+        if (gkey) axpy_frag(acc, gkey[ch], kf[i]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      float* p = &red[wave][256 * j + 4 * lane];
+      p[0] = acc.v[j].x; p[1] = acc.v[j].y; p[2] = acc.v[j].z; p[3] = acc.v[j].w;
+    }
+    if (lane == 0) red[wave][DCH * 256] = part_b;
+    __syncthreads();
+    if (wave == 0) {
+      RowFrag<DCH> tot;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        const int c = 256 * j + 4 * lane;
+        tot.v[j].x = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        tot.v[j].y = (red[0][c + 1] + red[1][c + 1]) + (red[2][c + 1] + red[3][c + 1]);
+        tot.v[j].z = (red[0][c + 2] + red[1][c + 2]) + (red[2][c + 2] + red[3][c + 2]);
+        tot.v[j].w = (red[0][c + 3] + red[1][c + 3]) + (red[2][c + 3] + red[3][c + 3]);
+      }
+      if (is_q) {
+        store_row(tot, b.slab_q + ((size_t)blockIdx.x * SR + s * a.R + r) * d, d, lane);
+      } else {
+        store_row(tot, b.slab + ((size_t)blockIdx.x * SE + s * a.E + e) * d, d, lane);
+        if (lane == 0) {
+          const int q = DCH * 256;
+          b.g_ebias_part[(size_t)blockIdx.x * SE + s * a.E + e] =
+              (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- backward: gather per sender
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_gather_bwd(ic_router_bwd_args b, int nslab) {
+  const ic_router_args& a = b.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  const int d = a.d, s = row / a.R, r = row % a.R;
+  const int SE = a.S * a.E, SR = a.S * a.R;
+  const bool prec = a.flags & IC_RF_PRECISION;
+  RowFrag<DCH> g, t;
+  zero_frag(g);
+  if (prec) {
+    load_row(g, b.gHd + (size_t)row * d, d, lane);
+    if (b.tape_qact[row]) {
+      for (int sl = 0; sl < nslab; ++sl) {
+        load_row(t, b.slab_q + ((size_t)sl * SR + row) * d, d, lane);
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          g.v[j].x += t.v[j].x; g.v[j].y += t.v[j].y; g.v[j].z += t.v[j].z; g.v[j].w += t.v[j].w;
+        }
+      }
+    }
+  }
+  if (a.mask_prev[row]) {
+    for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
+      const int e = b.src_edges[i];
+      for (int sl = 0; sl < nslab; ++sl) {
+        load_row(t, b.slab + ((size_t)sl * SE + s * a.E + e) * d, d, lane);
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          g.v[j].x += t.v[j].x; g.v[j].y += t.v[j].y; g.v[j].z += t.v[j].z; g.v[j].w += t.v[j].w;
+        }
+      }
+    }
+  }
+  store_row(g, b.gH + (size_t)row * d, d, lane);
+}
+
+// ---------------------------------------------------------------- deferred edge weight gradient
+template <int DCH>
+__global__ __launch_bounds__(256) void k_wgrad_edge(ic_wgrad_edge_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * 8 + wave * 2;
+  if (row0 >= d) return;
+  const int y = blockIdx.y;  // edge id (which<2) or region id (which==2)
+  const int n_g = a.which == 2 ? a.R : a.E;
+  const int hrow = a.which == 2 ? y : a.src[y];
+  const int m = a.which == 2 ? y : a.widx[y];
+  RowFrag<DCH> acc0, acc1, op;
+  zero_frag(acc0);
+  zero_frag(acc1);
+  bool any = false;
+  for (int t = 0; t < a.T; ++t) {
+    if (!a.visited[t]) continue;
+    for (int s = 0; s < a.S; ++s) {
+      const size_t gi = ((size_t)t * a.S + s) * n_g + y;
+      if (!a.tape_eact[gi]) continue;
+      any = true;
+      const float* g = a.tape_g + gi * d;
+      load_row(op, a.tape_H + (((size_t)t * a.S + s) * a.R + hrow) * d, d, lane);
+      axpy_frag(acc0, g[row0], op);
+      axpy_frag(acc1, g[row0 + 1], op);
+    }
+  }
+  if (!any) return;
+  float* out = a.gW + ((size_t)m * d + row0) * d;
+  const bool shared = (a.which != 2) && (a.nW != a.E);
+  if (shared) {  // several edges feed one matrix (by_direction): float atomics
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      const int c = 4 * lane + 256 * j;
+      if (c < d) {
+        atomicAdd(out + c, acc0.v[j].x); atomicAdd(out + c + 1, acc0.v[j].y);
+        atomicAdd(out + c + 2, acc0.v[j].z); atomicAdd(out + c + 3, acc0.v[j].w);
+        atomicAdd(out + d + c, acc1.v[j].x); atomicAdd(out + d + c + 1, acc1.v[j].y);
+        atomicAdd(out + d + c + 2, acc1.v[j].z); atomicAdd(out + d + c + 3, acc1.v[j].w);
+      }
+    }
+  } else {
+    RowFrag<DCH> cur;
+    load_row(cur, out, d, lane);
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      cur.v[j].x += acc0.v[j].x; cur.v[j].y += acc0.v[j].y; cur.v[j].z += acc0.v[j].z; cur.v[j].w += acc0.v[j].w;
+    }
+    store_row(cur, out, d, lane);
+    load_row(cur, out + d, d, lane);
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      cur.v[j].x += acc1.v[j].x; cur.v[j].y += acc1.v[j].y; cur.v[j].z += acc1.v[j].z; cur.v[j].w += acc1.v[j].w;
+    }
+    store_row(cur, out + d, d, lane);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.touched[m] = 1;
+}
+
+// W[widx[e]] += sum_b coef[b,e] * outer(H[b,dst_e], H[b,src_e])   (training.py:240-243)
+template <int DCH>
+__global__ __launch_bounds__(256) void k_hebbian(float* W, const int32_t* dst_of_edge,
+                                                 const int32_t* src, const int32_t* widx,
+                                                 const float* coef, const float* H, int B, int R,
+                                                 int d, int E) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 8 + wave * 2;
+  if (row0 >= d) return;
+  const int e = blockIdx.y;
+  float* out = W + ((size_t)widx[e] * d + row0) * d;
+  const int dst = dst_of_edge[e], sr = src[e];
+  RowFrag<DCH> w0, w1, pre;
+  bool loaded = false;
+  for (int bb = 0; bb < B; ++bb) {
+    const float c = coef[(size_t)bb * E + e];
+    if (c == 0.f) continue;
+    if (!loaded) {
+      load_row(w0, out, d, lane);
+      load_row(w1, out + d, d, lane);
+      loaded = true;
+    }
+    const float* post = H + ((size_t)bb * R + dst) * d;
+    load_row(pre, H + ((size_t)bb * R + sr) * d, d, lane);
+    const float p0 = post[row0], p1 = post[row0 + 1];
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {  // W.add_(c * outer(post, pre)), same rounding order
+      w0.v[j].x += c * (p0 * pre.v[j].x); w0.v[j].y += c * (p0 * pre.v[j].y);
+      w0.v[j].z += c * (p0 * pre.v[j].z); w0.v[j].w += c * (p0 * pre.v[j].w);
+      w1.v[j].x += c * (p1 * pre.v[j].x); w1.v[j].y += c * (p1 * pre.v[j].y);
+      w1.v[j].z += c * (p1 * pre.v[j].z); w1.v[j].w += c * (p1 * pre.v[j].w);
+    }
+  }
+  if (loaded) {
+    store_row(w0, out, d, lane);
+    store_row(w1, out + d, d, lane);
+  }
+}
+
+}  // namespace
+
+static int check_router(const ic_router_args* a, const char* who) {
+  IC_REQUIRE(a != nullptr, "%s: NULL args", who);
+  IC_REQUIRE(a->S > 0 && a->R > 0 && a->E >= 0, "%s: S=%d R=%d E=%d", who, a->S, a->R, a->E);
+  IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "%s: d=%d unsupported", who, a->d);
+  IC_REQUIRE(a->dst_off && a->H && a->mask_prev && a->M, "%s: NULL pointer", who);
+  IC_REQUIRE(a->E == 0 || (a->src && a->widx && a->W && a->ebias), "%s: NULL edge pointer", who);
+  if (a->flags & IC_RF_PRECISION)
+    IC_REQUIRE(a->key_W && a->query_W && a->raw_P && a->msg && a->keyv && a->q && a->wgt,
+               "%s: precision-routing buffers are NULL", who);
+  return IC_OK;
+}
+
+extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
+  int rc = check_router(a, "ic_router_fwd");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int nsl = ic_ceil_div(a->d, kRowsPerBlock);
+  if (a->flags & IC_RF_PRECISION) {
+    IC_DISPATCH_DCH(a->d, {
+      hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R), dim3(256), 0, st, *a);
+      hipLaunchKernelGGL(k_router_combine<DCH>, dim3(ic_ceil_div(a->S * a->R, 4)), dim3(256), 0, st, *a);
+    });
+  } else {
+    IC_DISPATCH_DCH(a->d, { hipLaunchKernelGGL(k_router_fwd<DCH>, dim3(nsl, a->R), dim3(256), 0, st, *a); });
+  }
+  IC_LAUNCH_CHECK("ic_router_fwd");
+  return IC_OK;
+}
+
+extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
+  IC_REQUIRE(b != nullptr, "ic_router_bwd: NULL args");
+  int rc = check_router(&b->f, "ic_router_bwd");
+  if (rc) return rc;
+  const ic_router_args* a = &b->f;
+  IC_REQUIRE(b->gM && b->gH && b->tape_H && b->tape_eact && b->src_off,
+             "ic_router_bwd: NULL gradient pointer");
+  IC_REQUIRE(a->E == 0 || (b->src_edges && b->g_ebias_part && b->tape_gmsg && b->slab),
+             "ic_router_bwd: NULL edge gradient pointer");
+  if (a->flags & IC_RF_PRECISION)
+    IC_REQUIRE(b->g_rawP_rows && b->tape_gkey && b->tape_gq && b->tape_qact && b->gHd && b->slab_q,
+               "ic_router_bwd: precision-routing gradient buffers are NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const int nslab = ic_bwd_nslab(a->d);
+  const dim3 blk(256), grow(ic_ceil_div(a->S * a->R, 4));
+  const int ny = a->E + ((a->flags & IC_RF_PRECISION) ? a->R : 0);
+  if (a->d <= 256) {
+    constexpr int DCH = 1;
+    hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b);
+    if (ny > 0) hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny), blk, 0, st, *b);
+    hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+  } else if (a->d <= 512) {
+    constexpr int DCH = 2;
+    hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b);
+    if (ny > 0) hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b);
+    hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+  } else {
+    constexpr int DCH = 4;
+    hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b);
+    if (ny > 0) hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b);
+    hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+  }
+  IC_LAUNCH_CHECK("ic_router_bwd");
+  return IC_OK;
+}
+
+extern "C" int ic_router_wgrad(const ic_wgrad_edge_args* a, ic_stream_t stream) {
+  IC_REQUIRE(a != nullptr, "ic_router_wgrad: NULL args");
+  IC_REQUIRE(a->T >= 0 && a->S > 0 && a->R > 0 && a->E >= 0 && a->nW >= 0, "ic_router_wgrad: bad dims");
+  IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "ic_router_wgrad: d=%d unsupported", a->d);
+  IC_REQUIRE(a->which >= 0 && a->which <= 2, "ic_router_wgrad: which=%d", a->which);
+  const int ny = a->which == 2 ? a->R : a->E;
+  if (a->T == 0 || ny == 0) return IC_OK;
+  IC_REQUIRE(a->tape_g && a->tape_H && a->tape_eact && a->visited && a->gW && a->touched,
+             "ic_router_wgrad: NULL pointer");
+  IC_REQUIRE(a->which == 2 || (a->src && a->widx), "ic_router_wgrad: NULL edge table");
+  IC_DISPATCH_DCH(a->d, {
+    hipLaunchKernelGGL(k_wgrad_edge<DCH>, dim3(ic_ceil_div(a->d, 8), ny), dim3(256), 0,
+                       (hipStream_t)stream, *a);
+  });
+  IC_LAUNCH_CHECK("ic_router_wgrad");
+  return IC_OK;
+}
+
+extern "C" int ic_hebbian_rank1(float* W, const int32_t* dst_of_edge, const int32_t* src,
+                                const int32_t* widx, const float* coef, const float* H, int32_t B,
+                                int32_t R, int32_t d, int32_t E, ic_stream_t stream) {
+  IC_REQUIRE(W && dst_of_edge && src && widx && coef && H, "ic_hebbian_rank1: NULL pointer");
+  IC_REQUIRE(d >= 4 && d % 4 == 0 && d <= 1024, "ic_hebbian_rank1: d=%d unsupported", d);
+  if (B <= 0 || E <= 0) return IC_OK;
+  IC_DISPATCH_DCH(d, {
+    hipLaunchKernelGGL(k_hebbian<DCH>, dim3(ic_ceil_div(d, 8), E), dim3(256), 0, (hipStream_t)stream,
+                       W, dst_of_edge, src, widx, coef, H, B, R, d, E);
+  });
+  IC_LAUNCH_CHECK("ic_hebbian_rank1");
+  return IC_OK;
+}

@@ -1,0 +1,136 @@
+"""ctypes binding of libironcortex_hip.so (the C ABI in include/ironcortex_hip.h).
+
+The struct layouts are parsed from the header at import time, so the Python side can
+never drift from the C declarations.  There is no CPU fallback: if the shared library is
+missing or a call returns an error code, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_REPO_DIR = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_PKG_DIR, "libironcortex_hip.so")
+HEADER_PATH = os.path.join(_REPO_DIR, "include", "ironcortex_hip.h")
+
+_SCALARS = {
+    "int32_t": ctypes.c_int32,
+    "int": ctypes.c_int,
+    "float": ctypes.c_float,
+    "double": ctypes.c_double,
+    "uint8_t": ctypes.c_uint8,
+}
+
+
+def _strip_comments(text: str) -> str:
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def parse_header(path: str = HEADER_PATH):
+    """Return ({struct name: [(field, ctype)]}, {enum name: value}, [function names])."""
+    text = _strip_comments(open(path).read())
+    enums: Dict[str, int] = {}
+    for body in re.findall(r"enum\s*\{(.*?)\}", text, flags=re.S):
+        nxt = 0
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                name, val = [t.strip() for t in item.split("=", 1)]
+                nxt = int(eval(val, {}, dict(enums)))  # literals / shifts of literals only
+            else:
+                name = item
+            enums[name] = nxt
+            nxt += 1
+    structs: Dict[str, List[Tuple[str, object]]] = {}
+    classes: Dict[str, type] = {}
+    for name, body in re.findall(r"typedef struct (\w+)\s*\{(.*?)\}\s*\w+;", text, flags=re.S):
+        fields: List[Tuple[str, object]] = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            decl = decl.replace("const ", "")
+            m = re.match(r"(\w+)\s*(.*)", decl)
+            base, rest = m.group(1), m.group(2)
+            all_ptr = "*" in decl  # the header never mixes pointers and values in one declaration
+            for var in rest.split(","):
+                var = var.replace("*", "").strip()
+                if all_ptr:
+                    fields.append((var, ctypes.c_void_p))
+                elif base in _SCALARS:
+                    fields.append((var, _SCALARS[base]))
+                elif base in classes:
+                    fields.append((var, classes[base]))
+                else:
+                    raise ValueError(f"cannot parse field '{decl}' in struct {name}")
+        structs[name] = fields
+        classes[name] = type(name, (ctypes.Structure,), {"_fields_": fields})
+    funcs = re.findall(r"^\s*(?:const char\*|int)\s+(ic_\w+)\s*\(", text, flags=re.M)
+    return structs, classes, enums, funcs
+
+
+STRUCTS, CLASSES, ENUMS, FUNCTIONS = parse_header()
+globals().update(ENUMS)
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C ironcortex_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback for the hot path"
+            )
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ic_last_error.restype = ctypes.c_char_p
+        for fn in FUNCTIONS:
+            if fn != "ic_last_error":
+                getattr(_lib, fn).restype = ctypes.c_int
+    return _lib
+
+
+def check(rc: int, who: str = "") -> None:
+    if rc != 0:
+        msg = lib().ic_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{who or 'ironcortex_hip'} failed (code {rc}): {msg}")
+
+
+def new(struct_name: str, **kw):
+    """Instantiate a C struct; tensors are converted to device pointers."""
+    obj = CLASSES[struct_name]()
+    for k, v in kw.items():
+        set_field(obj, k, v)
+    return obj
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("ironcortex_amd HIP ops need tensors on a ROCm device (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise RuntimeError("ironcortex_amd HIP ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def set_field(obj, name: str, value) -> None:
+    import torch
+
+    if isinstance(value, torch.Tensor):
+        value = ptr(value)
+    setattr(obj, name, value)
+
+
+def stream_handle():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
