@@ -1,0 +1,271 @@
+"""Generate golden vectors by running the REAL reference (read-only at /root/reference).
+
+Run once in the build container (the reference never travels to the GPU box):
+
+    cd /tmp && PYTHONPATH=/root/reference:/root/repo PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg \
+        python /root/repo/tests/golden/make_fixtures.py
+
+Only OUTPUTS are stored (tests/golden/*.npz); inputs come from tests/golden/inputs.py.
+Large matrix gradients are stored as two probe projections (dW @ p, q @ dW).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from tests.golden import inputs as gi  # noqa: E402
+
+from ironcortex.gate import Gate, Router  # noqa: E402  (the reference package)
+from ironcortex.region import RWKVRegionCell  # noqa: E402
+from ironcortex.utils import KWTA, nms_topk  # noqa: E402
+from ironcortex.wiring import hex_axial_coords, hex_neighbors  # noqa: E402
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, blob):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **blob)
+    print(f"wrote {path}: {len(blob)} arrays, {os.path.getsize(path)/1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------ F1/F3/F4: single region step
+def build_cell(case, t):
+    name, d, m_time, dt, afd, rt, noise_mode, step_pos = case
+    cell = RWKVRegionCell(
+        d, m_time_pairs=m_time, enable_adaptive_filter_dynamics=afd,
+        enable_radial_tangential_updates=rt, afd_noise_mode=noise_mode,
+    )
+    with torch.no_grad():
+        cell.r_lin.weight.copy_(t["Wr"]); cell.k_lin.weight.copy_(t["Wk"])
+        cell.v_lin.weight.copy_(t["Wv"]); cell.o_lin.weight.copy_(t["Wo"])
+        cell.norm.weight.copy_(t["norm_w"]); cell.raw_decay.copy_(t["raw_decay"])
+        cell.process_noise_param.copy_(t["pn_param"]); cell.obs_noise_param.copy_(t["on_param"])
+        cell.radius_process_noise_param.copy_(t["rpn_param"])
+        cell.radius_obs_noise_param.copy_(t["ron_param"])
+    return cell
+
+
+def region_fixture():
+    blob = {}
+    for ci, case in enumerate(gi.REGION_CASES):
+        name, d, m_time, dt, afd, rt, noise_mode, step_pos = case
+        t = gi.region_inputs(1000 + 100 * ci, d, noise_mode)
+        cell = build_cell(case, t)
+        leaves = {k: t[k].clone().requires_grad_(True) for k in ("num", "den", "var", "pred", "radius", "radius_var", "x_in")}
+        cell.state_num = leaves["num"] * 1.0
+        cell.state_den = leaves["den"] * 1.0
+        cell.state_var = leaves["var"] * 1.0
+        cell.pred = leaves["pred"] * 1.0
+        cell.radius = leaves["radius"] * 1.0
+        cell.radius_var = leaves["radius_var"] * 1.0
+        cell.surprise_ema = t["surprise"].clone()
+        cell.dt = dt
+        h = cell.step(leaves["x_in"], step_pos)
+        loss = (h * t["g_h"]).sum() + (cell.state_num * t["g_num"]).sum() + (cell.state_den * t["g_den"]).sum()
+        if afd:
+            loss = loss + (cell.state_var * t["g_var"]).sum()
+        if rt:
+            loss = loss + (cell.radius * t["g_radius"]).sum() + (cell.radius_var * t["g_radius_var"]).sum()
+        loss.backward()
+        pre = f"{name}."
+        blob[pre + "h"] = npy(h)
+        blob[pre + "num"] = npy(cell.state_num); blob[pre + "den"] = npy(cell.state_den)
+        blob[pre + "var"] = npy(cell.state_var); blob[pre + "pred"] = npy(cell.pred)
+        blob[pre + "radius"] = npy(cell.radius); blob[pre + "radius_var"] = npy(cell.radius_var)
+        blob[pre + "surprise"] = npy(cell.surprise_ema)
+        blob[pre + "dt"] = np.array(cell.dt)
+        if rt:
+            blob[pre + "last_dir"] = npy(cell.last_dir); blob[pre + "last_norm"] = npy(cell.last_norm)
+        for k, leaf in leaves.items():
+            if leaf.grad is not None:
+                blob[pre + "g." + k] = npy(leaf.grad)
+        for pname, par in (("norm_w", cell.norm.weight), ("raw_decay", cell.raw_decay),
+                           ("pn_param", cell.process_noise_param), ("on_param", cell.obs_noise_param),
+                           ("rpn_param", cell.radius_process_noise_param),
+                           ("ron_param", cell.radius_obs_noise_param)):
+            if par.grad is not None:
+                blob[pre + "g." + pname] = npy(par.grad)
+        for pname, lin in (("Wr", cell.r_lin), ("Wk", cell.k_lin), ("Wv", cell.v_lin), ("Wo", cell.o_lin)):
+            g = lin.weight.grad
+            if d <= 32:
+                blob[pre + "g." + pname] = npy(g)
+            blob[pre + "gp." + pname] = npy(g @ t["probe_p"])
+            blob[pre + "gq." + pname] = npy(t["probe_q"] @ g)
+    save("region.npz", blob)
+
+
+# ------------------------------------------------------------------ F2: 4-step chains with grads
+def chain_fixture():
+    blob = {}
+    for ci, (d, afd, rt) in enumerate([(8, True, False), (32, False, False), (32, True, True)]):
+        t = gi.region_inputs(5000 + 100 * ci, d, "scalar")
+        case = (f"chain{ci}", d, 16, 0, afd, rt, "scalar", 0.0)
+        cell = build_cell(case, t)
+        xs = gi.det(5050 + ci, 4, d).requires_grad_(True)
+        outs = []
+        for i in range(4):
+            if i == 2:  # a skipped micro-step in the middle exercises dt>0 and the trace
+                cell.predict(gi.det(5060 + ci, d))
+                cell.skip()
+            outs.append(cell.step(xs[i], i / 3.0))
+        loss = sum((o * gi.det(5070 + ci + 10 * i, d)).sum() for i, o in enumerate(outs))
+        loss.backward()
+        pre = f"chain{ci}."
+        blob[pre + "outs"] = npy(torch.stack(outs))
+        blob[pre + "num"] = npy(cell.state_num); blob[pre + "den"] = npy(cell.state_den)
+        blob[pre + "var"] = npy(cell.state_var); blob[pre + "radius"] = npy(cell.radius)
+        blob[pre + "g.xs"] = npy(xs.grad)
+        for pname, lin in (("Wr", cell.r_lin), ("Wk", cell.k_lin), ("Wv", cell.v_lin), ("Wo", cell.o_lin)):
+            blob[pre + "g." + pname] = npy(lin.weight.grad)
+        blob[pre + "g.norm_w"] = npy(cell.norm.weight.grad)
+        blob[pre + "g.raw_decay"] = npy(cell.raw_decay.grad)
+        if afd:
+            blob[pre + "g.pn_param"] = npy(cell.process_noise_param.grad)
+            blob[pre + "g.on_param"] = npy(cell.obs_noise_param.grad)
+        if rt:
+            blob[pre + "g.rpn_param"] = npy(cell.radius_process_noise_param.grad)
+            blob[pre + "g.ron_param"] = npy(cell.radius_obs_noise_param.grad)
+    save("chain.npz", blob)
+
+
+# ------------------------------------------------------------------ F5: KWTA
+def kwta_fixture():
+    blob = {}
+    for i, (d, k) in enumerate(gi.KWTA_CASES):
+        x = gi.kwta_rows(7000 + i, d)
+        blob[f"hard.{d}.{k}"] = npy(KWTA(x, k))
+        blob[f"soft.{d}.{k}"] = npy(KWTA(x, k, soft=True, temp=0.7))
+    blob["zero_k"] = npy(KWTA(gi.kwta_rows(7100, 32), 0))
+    save("kwta.npz", blob)
+
+
+# ------------------------------------------------------------------ F6: gate
+def gate_fixture():
+    blob = {}
+    for R in gi.GATE_R:
+        nb = hex_neighbors(R)
+        io = {"sensor": 0, "motor": R - 1}
+        gate = Gate(R, nb, io)
+        gate.gain_ema.copy_(gi.det(8000 + R, R, scale=0.2))
+        gate.homeo.copy_(gi.det(8001 + R, R, scale=0.05))
+        H = gi.det(8002 + R, R, 16)
+        H[R // 2:] = 0.0  # half the regions silent, like a real inner step
+        for fi, (focus_any, vb, um) in enumerate([(True, 0.13, 0.41), (False, -0.2, 0.0)]):
+            gate.value_bias = vb
+            focus = torch.zeros(5, dtype=torch.bool)
+            focus[2] = focus_any
+            sc = gate.score_regions(H, focus, um)
+            blob[f"scores.{R}.{fi}"] = npy(sc)
+            for k_active in (2, 4, 8, 32):
+                for burst in (0, max(1, R // 8)):
+                    m = gate.select_k(sc, k_active, burst)
+                    blob[f"mask.{R}.{fi}.{k_active}.{burst}"] = npy(m)
+        # exact-tie inputs: record the reference's (unstable) walk for documentation
+        z = torch.zeros(R)
+        blob[f"tie_zero.{R}"] = np.array(nms_topk(z, 6, nb))
+        z2 = z.clone(); z2[0] = 0.5; z2[R - 1] = 0.5
+        blob[f"tie_two.{R}"] = np.array(nms_topk(z2, 6, nb))
+    save("gate.npz", blob)
+
+
+# ------------------------------------------------------------------ F7: router
+def router_fixture():
+    blob = {}
+    for ci, (name, R, d, mode, prec) in enumerate(gi.ROUTER_CASES):
+        nb = hex_neighbors(R)
+        coords = hex_axial_coords(R)
+        router = Router(nb, d, R, enable_precision_routed_messages=prec, edge_transform_mode=mode)
+        E = len(router.edge_keys)
+        t = gi.router_inputs(9000 + 100 * ci, R, d, E, mode)
+        with torch.no_grad():
+            router.W_reg.copy_(t["W_reg"]); router.beta_cos.copy_(t["beta_cos"]); router.beta_sin.copy_(t["beta_sin"])
+            for r in range(R):
+                router.query_lin[r].weight.copy_(t["query_W"][r])
+            if mode == "per_edge":
+                for e, k in enumerate(router.edge_keys):
+                    router.W_edge[k].weight.copy_(t["W_edge"][e]); router.key_lin[k].weight.copy_(t["key_W"][e])
+                    router.raw_P_edge[k].copy_(t["raw_P"][e])
+            elif mode == "by_direction":
+                for i in range(6):
+                    router.W_dir[i].weight.copy_(t["W_dir"][i]); router.key_lin_dir[i].weight.copy_(t["key_W"][i])
+                    router.raw_P_dir[i].copy_(t["raw_P"][i])
+            else:
+                router.U.weight.copy_(t["U"]); router.V.weight.copy_(t["V"])
+                for e, k in enumerate(router.edge_keys):
+                    router.w_edge[k].copy_(t["w_edge"][e]); router.key_lin[k].weight.copy_(t["key_W"][e])
+                    router.raw_P_edge[k].copy_(t["raw_P"][e])
+        H = t["H"].clone().requires_grad_(True)
+        M = router.messages(H, t["mask_prev"], coords)
+        (M * t["g_M"]).sum().backward()
+        pre = name + "."
+        blob[pre + "M"] = npy(M)
+        blob[pre + "g.H"] = npy(H.grad)
+        w = torch.zeros(E)
+        for e, k in enumerate(router.edge_keys):
+            if k in router.last_weights:
+                w[e] = router.last_weights[k]
+        blob[pre + "weights"] = npy(w)
+        blob[pre + "g.beta_cos"] = npy(router.beta_cos.grad); blob[pre + "g.beta_sin"] = npy(router.beta_sin.grad)
+        zeros = torch.zeros(d, d)
+        if mode == "per_edge":
+            blob[pre + "g.W_edge"] = npy(torch.stack([router.W_edge[k].weight.grad if router.W_edge[k].weight.grad is not None else zeros for k in router.edge_keys]))
+        elif mode == "by_direction":
+            blob[pre + "g.W_dir"] = npy(torch.stack([l.weight.grad if l.weight.grad is not None else zeros for l in router.W_dir]))
+        else:
+            blob[pre + "g.U"] = npy(router.U.weight.grad); blob[pre + "g.V"] = npy(router.V.weight.grad)
+            blob[pre + "g.w_edge"] = npy(torch.stack([router.w_edge[k].grad if router.w_edge[k].grad is not None else torch.zeros(d) for k in router.edge_keys]))
+        if prec:
+            blob[pre + "g.query_W"] = npy(torch.stack([l.weight.grad if l.weight.grad is not None else zeros for l in router.query_lin]))
+            if mode == "by_direction":
+                blob[pre + "g.key_W"] = npy(torch.stack([l.weight.grad if l.weight.grad is not None else zeros for l in router.key_lin_dir]))
+                blob[pre + "g.raw_P"] = npy(torch.stack([p.grad if p.grad is not None else torch.zeros(d) for p in router.raw_P_dir]))
+            else:
+                blob[pre + "g.key_W"] = npy(torch.stack([router.key_lin[k].weight.grad if router.key_lin[k].weight.grad is not None else zeros for k in router.edge_keys]))
+                blob[pre + "g.raw_P"] = npy(torch.stack([router.raw_P_edge[k].grad if router.raw_P_edge[k].grad is not None else torch.zeros(d) for k in router.edge_keys]))
+    # reference known-answer: precision routing down-weights the inconsistent neighbour
+    # (tests/test_router_precision.py:46-65)
+    R, d = 3, 4
+    router = Router([[1], [0, 2], [1]], d, R, enable_precision_routed_messages=True)
+    router.fb_alpha = 0.0
+    for r in range(R):
+        router.query_lin[r].weight.data = torch.eye(d)
+    for lin in router.key_lin.values():
+        lin.weight.data = torch.eye(d)
+    for lin in router.W_edge.values():
+        lin.weight.data = torch.eye(d) * 0.5
+    for p in router.raw_P_edge.values():
+        p.data.fill_(1.0)
+    H = torch.zeros(R, d); H[2] = 5.0; H[0] = 0.25
+    M = router.messages(H, torch.ones(R, dtype=torch.bool), torch.zeros(R, 2))
+    blob["line3.M"] = npy(M)
+    blob["line3.w01"] = np.array(router.last_weights["0->1"]); blob["line3.w21"] = np.array(router.last_weights["2->1"])
+    save("router.npz", blob)
+
+
+# ------------------------------------------------------------------ F8: wiring
+def wiring_fixture():
+    blob = {}
+    for R in (1, 2, 7, 10, 36, 64, 128, 256, 512):
+        blob[f"coords.{R}"] = npy(hex_axial_coords(R))
+        nb = hex_neighbors(R)
+        flat = np.full((R, 6), -1, dtype=np.int32)
+        for i, row in enumerate(nb):
+            flat[i, : len(row)] = row
+        blob[f"nbr.{R}"] = flat
+    save("wiring.npz", blob)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["region", "chain", "kwta", "gate", "router", "wiring"]
+    for w in which:
+        globals()[w + "_fixture"]()
