@@ -1,0 +1,507 @@
+"""torch.autograd.Function wrappers over the C ABI (include/ironcortex_hip.h).
+
+Each Function's forward/backward is one C call (a handful of kernel launches); weight
+gradients are deferred to one ic_*_wgrad launch per backward pass through a tape
+(see GradCoordinator).  No op here has a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ENUMS, check, lib, new, stream_handle
+
+IC_F_AFD = ENUMS["IC_F_AFD"]
+IC_F_RT = ENUMS["IC_F_RT"]
+IC_F_PRED = ENUMS["IC_F_PRED"]
+IC_F_NOKWTA = ENUMS["IC_F_NOKWTA"]
+IC_F_KWTA_SOFT = ENUMS["IC_F_KWTA_SOFT"]
+IC_F_NOISE_VEC = ENUMS["IC_F_NOISE_VEC"]
+IC_F_NORM_IN = ENUMS["IC_F_NORM_IN"]
+IC_RF_PRECISION = ENUMS["IC_RF_PRECISION"]
+
+
+def _call(name: str, args) -> None:
+    check(getattr(lib(), name)(ctypes.byref(args), stream_handle()), name)
+
+
+def bwd_nslab(d: int) -> int:
+    return int(lib().ic_bwd_nslab(ctypes.c_int32(d)))
+
+
+# ============================================================================ coordination
+class GradCoordinator:
+    """Runs the deferred weight-gradient launches once per backward pass.
+
+    Function.backward calls begin(); the first call of a pass zeroes the gradient slices that
+    start from None and queues an end-of-pass callback on the autograd engine."""
+
+    def __init__(self):
+        self._pending = False
+        self._begin: List[Callable[[], None]] = []
+        self._finish: List[Callable[[], None]] = []
+
+    def register(self, begin: Callable[[], None], finish: Callable[[], None]) -> None:
+        self._begin.append(begin)
+        self._finish.append(finish)
+
+    def begin(self) -> None:
+        if self._pending:
+            return
+        self._pending = True
+        for f in self._begin:
+            f()
+        torch.autograd.Variable._execution_engine.queue_callback(self._end)
+
+    def _end(self) -> None:
+        try:
+            for f in self._finish:
+                f()
+        finally:
+            self._pending = False
+
+
+class Tape:
+    """Per-step gradient vectors kept until the end of the backward pass.
+
+    fields: name -> per-slot shape; storage grows geometrically.  A slot is allocated in the
+    forward of every differentiable call and marked visited by its backward."""
+
+    def __init__(self, fields: Dict[str, tuple], dtypes: Optional[Dict[str, torch.dtype]] = None):
+        self.fields = fields
+        self.dtypes = dtypes or {}
+        self.cap = 0
+        self.pos = 0
+        self.buf: Dict[str, torch.Tensor] = {}
+        self.visited: torch.Tensor = None  # type: ignore
+
+    def _grow(self, device, need: int) -> None:
+        cap = max(64, self.cap)
+        while cap < need:
+            cap *= 2
+        for name, shape in self.fields.items():
+            dt = self.dtypes.get(name, torch.float32)
+            nb = torch.zeros((cap,) + tuple(shape), dtype=dt, device=device)
+            if self.cap and name in self.buf and self.buf[name].device == nb.device:
+                nb[: self.cap].copy_(self.buf[name])
+            self.buf[name] = nb
+        nv = torch.zeros(cap, dtype=torch.uint8, device=device)
+        if self.cap and self.visited is not None and self.visited.device == nv.device:
+            nv[: self.cap].copy_(self.visited)
+        self.visited = nv
+        self.cap = cap
+
+    def alloc(self, device) -> int:
+        if self.pos + 1 > self.cap or (self.visited is not None and self.visited.device != device):
+            if self.visited is not None and self.visited.device != device:
+                self.cap, self.pos = 0, 0
+            self._grow(device, self.pos + 1)
+        t = self.pos
+        self.pos += 1
+        return t
+
+    def slot(self, name: str, t: int) -> torch.Tensor:
+        return self.buf[name][t]
+
+    def reset(self) -> None:
+        if self.pos:
+            self.visited[: self.pos].zero_()
+        self.pos = 0
+
+
+def _z(like: torch.Tensor, *shape, dtype=None) -> torch.Tensor:
+    return torch.zeros(shape, dtype=dtype or torch.float32, device=like.device)
+
+
+def _e(like: torch.Tensor, *shape, dtype=None) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype or torch.float32, device=like.device)
+
+
+# ============================================================================ region phase
+class RegionPhaseSpec:
+    """Static description of a bank of region cells + per-call scalars."""
+
+    def __init__(self, R: int, d: int, m_time: int, flags: int, sensor_idx: int = -1, motor_idx: int = -1):
+        self.R, self.d, self.m_time, self.flags = R, d, m_time, flags
+        self.sensor_idx, self.motor_idx = sensor_idx, motor_idx
+        self.pred_alpha = 0.95
+
+
+def _region_args(spec: RegionPhaseSpec, P: Dict[str, torch.Tensor], S: int, step_pos: float, kwta_k: int,
+                 flags: int, kwta_temp: float):
+    a = new("ic_region_args", S=S, R=spec.R, d=spec.d, m_time=spec.m_time, kwta_k=kwta_k, flags=flags,
+            sensor_idx=spec.sensor_idx, motor_idx=spec.motor_idx, rows_fwd=0, step_pos=float(step_pos),
+            kwta_temp=float(kwta_temp), pred_alpha=float(spec.pred_alpha))
+    for k in ("W", "norm_w", "raw_decay", "norm_in_w", "W_time", "pn_param", "on_param", "rpn_param", "ron_param"):
+        t = P.get(k)
+        if t is not None and t.numel() > 0:
+            setattr(a, k, t.data_ptr())
+    return a
+
+
+class RegionPhaseFn(torch.autograd.Function):
+    """ic_region_phase_fwd / ic_region_phase_bwd.
+
+    forward(anchor, M, sensor, norm_in_w, num, den, var, pred, radius, radius_var, box)
+      -> (H, num', den', var', pred', radius', radius_var')     (None where a feature is off)
+    box carries the non-differentiable context (spec, parameter tensors, mask, dt, ...).
+    """
+
+    @staticmethod
+    def forward(ctx, anchor, M, sensor, norm_in_w, num, den, var, pred, radius, radius_var, box):
+        spec: RegionPhaseSpec = box["spec"]
+        P = dict(box["P"])
+        if norm_in_w is not None:
+            P["norm_in_w"] = norm_in_w
+        S = M.shape[0]
+        R, d = spec.R, spec.d
+        flags = box["flags"]
+        afd, rt, use_pred = bool(flags & IC_F_AFD), bool(flags & IC_F_RT), bool(flags & IC_F_PRED)
+        mask, dt, surprise = box["mask"], box["dt"], box["surprise"]
+        cont = lambda t: None if t is None else t.contiguous()
+        M, sensor, num, den, var, pred = cont(M), cont(sensor), cont(num), cont(den), cont(var), cont(pred)
+        radius, radius_var = cont(radius), cont(radius_var)
+        a = _region_args(spec, P, S, box["step_pos"], box["kwta_k"], flags, box["kwta_temp"])
+        H = _e(M, S, R, d)
+        num_o, den_o = _e(M, S, R, d), _e(M, S, R, d)
+        var_o = _e(M, S, R, d) if afd else None
+        pred_o = _e(M, S, R, d) if use_pred else None
+        radius_o = _e(M, S, R) if rt else None
+        radius_var_o = _e(M, S, R) if rt else None
+        surprise_o = _e(M, S, R) if afd else None
+        last_dir = _z(M, S, R, d) if rt else None
+        last_norm = _z(M, S, R) if rt else None
+        dt_o = torch.empty_like(dt)
+        sv = {k: _e(M, S, R, d) for k in ("x", "u1", "r_s", "k_s", "v_s", "y", "hpre", "gate")}
+        sv["inv_s"] = _e(M, S, R, 2)
+        if rt:
+            sv["ynorm"] = _e(M, S, R)
+        if afd:
+            sv["sterm"] = _e(M, S, R, d)
+        tensors = dict(M=M, sensor=sensor, mask=mask, num=num, den=den, var=var, pred=pred, radius=radius,
+                       radius_var=radius_var, surprise=surprise, dt=dt, H=H, num_o=num_o, den_o=den_o,
+                       var_o=var_o, pred_o=pred_o, radius_o=radius_o, radius_var_o=radius_var_o,
+                       surprise_o=surprise_o, last_dir=last_dir, last_norm=last_norm, dt_o=dt_o, **sv)
+        for k, t in tensors.items():
+            if t is not None:
+                setattr(a, k, t.data_ptr())
+        _call("ic_region_phase_fwd", a)
+        box["dt_o"], box["surprise_o"] = dt_o, surprise_o
+        box["last_dir"], box["last_norm"] = last_dir, last_norm
+        box["H_detached"] = H
+        needs = any(t is not None and t.requires_grad for t in (anchor, M, sensor, num, den, var, pred, radius, radius_var))
+        if needs:
+            tape: Tape = box["tape"]
+            slot = tape.alloc(M.device)
+            tape.slot("mask", slot).copy_(mask)
+            ctx.slot = slot
+            ctx.box = box
+            ctx.sv = sv
+            ctx.P = P
+            ctx.flags = flags
+            ctx.has = (sensor is not None, norm_in_w is not None)
+            ctx.saved_in = (M, sensor, num, den, var, pred, radius, radius_var, radius_o)
+        outs = (H, num_o, den_o, var_o, pred_o, radius_o, radius_var_o)
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, gH, gnum_o, gden_o, gvar_o, gpred_o, gradius_o, gradius_var_o):
+        box = ctx.box
+        spec: RegionPhaseSpec = box["spec"]
+        coord: GradCoordinator = box["coord"]
+        coord.begin()
+        M, sensor, num, den, var, pred, radius, radius_var, radius_o = ctx.saved_in
+        S, R, d = M.shape
+        flags = ctx.flags
+        afd, rt, use_pred = bool(flags & IC_F_AFD), bool(flags & IC_F_RT), bool(flags & IC_F_PRED)
+        norm_in = bool(flags & IC_F_NORM_IN)
+        tape: Tape = box["tape"]
+        slot = ctx.slot
+        tape.visited[slot:slot + 1].fill_(1)
+        b = new("ic_region_bwd_args")
+        b.f = _region_args(spec, ctx.P, S, box["step_pos"], box["kwta_k"], flags, box["kwta_temp"])
+        fin = dict(M=M, sensor=sensor, mask=box["mask"], num=num, den=den, var=var, pred=pred, radius=radius,
+                   radius_var=radius_var, dt=box["dt"], radius_o=radius_o, **ctx.sv)
+        for k, t in fin.items():
+            if t is not None:
+                setattr(b.f, k, t.data_ptr())
+        cont = lambda t: None if t is None else t.contiguous()
+        gin = dict(gH=cont(gH), gnum_o=cont(gnum_o), gden_o=cont(gden_o), gvar_o=cont(gvar_o),
+                   gpred_o=cont(gpred_o), gradius_o=cont(gradius_o), gradius_var_o=cont(gradius_var_o))
+        nslab = bwd_nslab(d)
+        out = dict(gM=_e(M, S, R, d), gnum=_e(M, S, R, d), gden=_e(M, S, R, d),
+                   g_norm_w_rows=_z(M, S, R, d), g_raw_decay_rows=_z(M, S, R, d),
+                   ghpre=_e(M, S, R, d), gy=_e(M, S, R, d), slab=_e(M, nslab, S, R, d))
+        if use_pred:
+            out["gpred"] = _e(M, S, R, d)
+        if norm_in:
+            out["g_norm_in_rows"] = _z(M, S, R, d)
+            if ctx.has[0]:
+                out["gsens"] = _z(M, S, 2, d)
+        if afd:
+            out.update(gvar=_e(M, S, R, d), g_pn_rows=_z(M, S, R, d), g_on_rows=_z(M, S, R, d))
+        if rt:
+            out.update(gradius=_e(M, S, R), gradius_var=_e(M, S, R), g_rnoise_rows=_z(M, S, R, 2),
+                       slab_rt=_e(M, nslab, S, R))
+        keep = []
+        for k, t in {**gin, **out}.items():
+            if t is not None:
+                keep.append(t)
+                setattr(b, k, t.data_ptr())
+        b.tape_g = tape.slot("g", slot).data_ptr()
+        b.tape_x = tape.slot("x", slot).data_ptr()
+        b.tape_o = tape.slot("o", slot).data_ptr()
+        _call("ic_region_phase_bwd", b)
+        # small per-region parameter gradients go straight into the gradient arena
+        sink = box["grad_sink"]
+        sink("norm_w", out["g_norm_w_rows"].sum(0))
+        sink("raw_decay", out["g_raw_decay_rows"].sum(0))
+        if afd:
+            if flags & IC_F_NOISE_VEC:
+                sink("pn_param", out["g_pn_rows"].sum(0))
+                sink("on_param", out["g_on_rows"].sum(0))
+            else:
+                sink("pn_param", out["g_pn_rows"].sum((0, 2)))
+                sink("on_param", out["g_on_rows"].sum((0, 2)))
+        if rt:
+            rn = out["g_rnoise_rows"].sum(0)
+            sink("rpn_param", rn[:, 0].contiguous())
+            sink("ron_param", rn[:, 1].contiguous())
+        g_sensor = out["gsens"].sum(1) if (norm_in and ctx.has[0]) else None
+        g_norm_in = out["g_norm_in_rows"].sum((0, 1)) if (norm_in and ctx.has[1]) else None
+        return (None, out["gM"], g_sensor, g_norm_in, out["gnum"], out["gden"], out.get("gvar"),
+                out.get("gpred"), out.get("gradius"), out.get("gradius_var"), None)
+
+
+def region_wgrad(tape: Tape, S: int, R: int, d: int, gW: torch.Tensor, touched: torch.Tensor) -> None:
+    if tape.pos == 0:
+        return
+    a = new("ic_wgrad_region_args", T=tape.pos, S=S, R=R, d=d, tape_g=tape.buf["g"], tape_x=tape.buf["x"],
+            tape_o=tape.buf["o"], mask=tape.buf["mask"], visited=tape.visited, gW=gW, touched=touched)
+    _call("ic_region_wgrad", a)
+
+
+# ============================================================================ router
+class RouterSpec:
+    def __init__(self, R: int, d: int, E: int, nW: int, precision: bool):
+        self.R, self.d, self.E, self.nW, self.precision = R, d, E, nW, precision
+
+
+def _router_args(spec: RouterSpec, T: Dict[str, torch.Tensor], P: Dict[str, torch.Tensor], S: int):
+    a = new("ic_router_args", S=S, R=spec.R, d=spec.d, E=spec.E, flags=IC_RF_PRECISION if spec.precision else 0)
+    a.dst_off, a.src, a.widx = T["dst_off"].data_ptr(), T["src"].data_ptr(), T["widx"].data_ptr()
+    a.W = P["W"].data_ptr()
+    if spec.precision:
+        a.key_W, a.query_W, a.raw_P = P["key_W"].data_ptr(), P["query_W"].data_ptr(), P["raw_P"].data_ptr()
+    return a
+
+
+class RouterFn(torch.autograd.Function):
+    """ic_router_fwd / ic_router_bwd.   forward(anchor, H, ebias, box) -> M"""
+
+    @staticmethod
+    def forward(ctx, anchor, H, ebias, box):
+        spec: RouterSpec = box["spec"]
+        S = H.shape[0]
+        R, d, E = spec.R, spec.d, spec.E
+        H = H.contiguous()
+        ebias = ebias.contiguous()
+        a = _router_args(spec, box["tables"], box["P"], S)
+        M = _e(H, S, R, d)
+        a.H, a.mask_prev, a.M, a.ebias = H.data_ptr(), box["mask_prev"].data_ptr(), M.data_ptr(), ebias.data_ptr()
+        sv = {}
+        if spec.precision:
+            sv = dict(msg=_e(H, S, E, d), keyv=_e(H, S, E, d), q=_e(H, S, R, d), wgt=_z(H, S, E))
+            for k, t in sv.items():
+                setattr(a, k, t.data_ptr())
+        if E > 0:
+            _call("ic_router_fwd", a)
+        else:
+            M.zero_()
+        box["wgt"] = sv.get("wgt")
+        if H.requires_grad or ebias.requires_grad or (anchor is not None and anchor.requires_grad):
+            tape: Tape = box["tape"]
+            ctx.slot = tape.alloc(H.device)
+            ctx.box, ctx.sv, ctx.saved_in = box, sv, (H, ebias)
+        return M
+
+    @staticmethod
+    def backward(ctx, gM):
+        box = ctx.box
+        spec: RouterSpec = box["spec"]
+        box["coord"].begin()
+        H, ebias = ctx.saved_in
+        S, R, d, E = H.shape[0], spec.R, spec.d, spec.E
+        tape: Tape = box["tape"]
+        slot = ctx.slot
+        if E == 0:
+            return None, torch.zeros_like(H), torch.zeros_like(ebias), None
+        tape.visited[slot:slot + 1].fill_(1)
+        b = new("ic_router_bwd_args")
+        b.f = _router_args(spec, box["tables"], box["P"], S)
+        b.f.H, b.f.mask_prev, b.f.ebias = H.data_ptr(), box["mask_prev"].data_ptr(), ebias.data_ptr()
+        b.f.M = gM.data_ptr()  # unused by the backward, must be non-NULL
+        for k, t in ctx.sv.items():
+            setattr(b.f, k, t.data_ptr())
+        nslab = bwd_nslab(d)
+        gM = gM.contiguous()
+        out = dict(gH=_e(H, S, R, d), g_ebias_part=_z(H, nslab, S, E), slab=_e(H, nslab, S, E, d))
+        if spec.precision:
+            out.update(g_rawP_rows=_z(H, S, E, d), gHd=_e(H, S, R, d), slab_q=_e(H, nslab, S, R, d))
+        b.gM = gM.data_ptr()
+        for k, t in out.items():
+            setattr(b, k, t.data_ptr())
+        b.src_off, b.src_edges = box["tables"]["src_off"].data_ptr(), box["tables"]["src_edges"].data_ptr()
+        b.tape_gmsg = tape.slot("gmsg", slot).data_ptr()
+        b.tape_H = tape.slot("H", slot).data_ptr()
+        b.tape_eact = tape.slot("eact", slot).data_ptr()
+        if spec.precision:
+            b.tape_gkey = tape.slot("gkey", slot).data_ptr()
+            b.tape_gq = tape.slot("gq", slot).data_ptr()
+            b.tape_qact = tape.slot("qact", slot).data_ptr()
+        _call("ic_router_bwd", b)
+        if spec.precision:
+            box["grad_sink"]("raw_P", out["g_rawP_rows"].sum(0), box["tables"]["widx_long"])
+        g_ebias = out["g_ebias_part"].sum((0, 1))
+        return None, out["gH"], g_ebias, None
+
+
+def router_wgrad(tape: Tape, spec: RouterSpec, tables: Dict[str, torch.Tensor], S: int, which: int,
+                 gW: torch.Tensor, touched: torch.Tensor) -> None:
+    if tape.pos == 0 or spec.E == 0:
+        return
+    gname = ("gmsg", "gkey", "gq")[which]
+    a = new("ic_wgrad_edge_args", T=tape.pos, S=S, R=spec.R, d=spec.d, E=spec.E, nW=spec.nW, which=which,
+            dst_off=tables["dst_off"], src=tables["src"], widx=tables["widx"], tape_g=tape.buf[gname],
+            tape_H=tape.buf["H"], tape_eact=tape.buf["qact" if which == 2 else "eact"], visited=tape.visited,
+            gW=gW, touched=touched)
+    _call("ic_router_wgrad", a)
+
+
+# ============================================================================ gate
+def gate_scores_select(H: torch.Tensor, gain_ema: torch.Tensor, homeo: torch.Tensor,
+                       focus_any: Optional[torch.Tensor], nbr_off: torch.Tensor, nbr: torch.Tensor,
+                       sensor_idx: int, motor_idx: int, k_total: int, force_io: bool, t5: float, t6: float,
+                       weights=(1.0, 0.3, 0.5, 0.2), select: bool = True, scores: Optional[torch.Tensor] = None):
+    """Gate.score_regions (+ select_k).  H [S,R,d] -> (scores [S,R], mask uint8 [S,R])."""
+    S, R, d = H.shape
+    H = H.detach().contiguous()
+    mask = _e(H, S, R, dtype=torch.uint8)
+    a = new("ic_gate_args", S=S, R=R, d=d, sensor_idx=sensor_idx, motor_idx=motor_idx, k_total=int(k_total),
+            force_io=int(bool(force_io)), w1=weights[0], w2=weights[1], w3=weights[2], w4=weights[3],
+            t5=float(t5), t6=float(t6), H=H, gain_ema=gain_ema, homeo=homeo, focus_any=focus_any,
+            nbr_off=nbr_off, nbr=nbr, mask=mask)
+    if scores is None:
+        scores = _e(H, S, R)
+        a.scores = scores.data_ptr()
+        _call("ic_gate_scores", a)
+    else:
+        scores = scores.contiguous()
+        a.scores = scores.data_ptr()
+    if select:
+        _call("ic_gate_select", a)
+    return scores, mask
+
+
+# ============================================================================ primitives
+class KWTAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, soft, temp):
+        shape = x.shape
+        d = shape[-1]
+        x2 = x.contiguous().view(-1, d)
+        y, gate = torch.empty_like(x2), torch.empty_like(x2)
+        check(lib().ic_kwta_fwd(ctypes.c_void_p(x2.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                ctypes.c_void_p(gate.data_ptr()), ctypes.c_int32(x2.shape[0]),
+                                ctypes.c_int32(d), ctypes.c_int32(int(k)), ctypes.c_int32(int(bool(soft))),
+                                ctypes.c_float(float(temp)), stream_handle()), "ic_kwta_fwd")
+        ctx.save_for_backward(gate)
+        ctx.soft = bool(soft)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (gate,) = ctx.saved_tensors
+        if ctx.soft:
+            raise RuntimeError("soft KWTA is differentiable only inside the fused region step")
+        d = gate.shape[-1]
+        g2 = gy.contiguous().view(-1, d)
+        gx = torch.empty_like(g2)
+        check(lib().ic_kwta_bwd(None, ctypes.c_void_p(gate.data_ptr()), ctypes.c_void_p(g2.data_ptr()),
+                                ctypes.c_void_p(gx.data_ptr()), ctypes.c_int32(g2.shape[0]), ctypes.c_int32(d),
+                                ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_float(1.0), stream_handle()),
+              "ic_kwta_bwd")
+        return gx.view(gy.shape), None, None, None
+
+
+class RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        shape = x.shape
+        d = shape[-1]
+        x2 = x.contiguous().view(-1, d)
+        w = w.contiguous()
+        y = torch.empty_like(x2)
+        inv = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+        check(lib().ic_rmsnorm_fwd(ctypes.c_void_p(x2.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                   ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(inv.data_ptr()),
+                                   ctypes.c_int32(x2.shape[0]), ctypes.c_int32(d), ctypes.c_float(float(eps)),
+                                   stream_handle()), "ic_rmsnorm_fwd")
+        ctx.save_for_backward(x2, w, inv)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, inv = ctx.saved_tensors
+        d = x2.shape[-1]
+        g2 = gy.contiguous().view(-1, d)
+        gx, gw_rows = torch.empty_like(x2), torch.empty_like(x2)
+        check(lib().ic_rmsnorm_bwd(ctypes.c_void_p(x2.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                   ctypes.c_void_p(inv.data_ptr()), ctypes.c_void_p(g2.data_ptr()),
+                                   ctypes.c_void_p(gx.data_ptr()), ctypes.c_void_p(gw_rows.data_ptr()),
+                                   ctypes.c_int32(x2.shape[0]), ctypes.c_int32(d), stream_handle()),
+              "ic_rmsnorm_bwd")
+        return gx.view(gy.shape), gw_rows.sum(0), None
+
+
+class GoodnessFn(torch.autograd.Function):
+    """mean_d H^2 per row (training.py:127-128)."""
+
+    @staticmethod
+    def forward(ctx, H):
+        d = H.shape[-1]
+        h2 = H.contiguous().view(-1, d)
+        g = torch.empty(h2.shape[0], dtype=torch.float32, device=H.device)
+        check(lib().ic_goodness_fwd(ctypes.c_void_p(h2.data_ptr()), ctypes.c_void_p(g.data_ptr()),
+                                    ctypes.c_int32(h2.shape[0]), ctypes.c_int32(d), stream_handle()),
+              "ic_goodness_fwd")
+        ctx.save_for_backward(h2)
+        ctx.shape = H.shape
+        return g.view(H.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, gg):
+        (h2,) = ctx.saved_tensors
+        d = h2.shape[-1]
+        gg = gg.contiguous().view(-1)
+        gH = torch.empty_like(h2)
+        check(lib().ic_goodness_bwd(ctypes.c_void_p(h2.data_ptr()), ctypes.c_void_p(gg.data_ptr()),
+                                    ctypes.c_void_p(gH.data_ptr()), ctypes.c_int32(h2.shape[0]),
+                                    ctypes.c_int32(d), stream_handle()), "ic_goodness_bwd")
+        return gH.view(ctx.shape)
+
+
+def hebbian_rank1(W: torch.Tensor, dst_of_edge: torch.Tensor, src: torch.Tensor, widx: torch.Tensor,
+                  coef: torch.Tensor, H: torch.Tensor) -> None:
+    """In-place W[widx[e]] += sum_b coef[b,e] * outer(H[b,dst_e], H[b,src_e])."""
+    B, R, d = H.shape
+    E = src.shape[0]
+    check(lib().ic_hebbian_rank1(ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(dst_of_edge.data_ptr()),
+                                 ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(widx.data_ptr()),
+                                 ctypes.c_void_p(coef.contiguous().data_ptr()),
+                                 ctypes.c_void_p(H.contiguous().data_ptr()), ctypes.c_int32(B),
+                                 ctypes.c_int32(R), ctypes.c_int32(d), ctypes.c_int32(E), stream_handle()),
+          "ic_hebbian_rank1")
