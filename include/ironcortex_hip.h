@@ -277,6 +277,16 @@ int ic_hebbian_rank1(float* W, const int32_t* dst_of_edge, const int32_t* src, c
                      const float* coef, const float* H, int32_t B, int32_t R, int32_t d, int32_t E,
                      ic_stream_t stream);
 
+/* ------------------------------------------------------------------ measurement hooks
+ * No counterpart in the reference (its cfg.profile timers read perf_counter without a device
+ * sync, model.py:219-294).  When enabled every kernel launch of this library is bracketed by
+ * HIP events on its own stream; ic_prof_read() synchronises on them and returns the number of
+ * launches and their summed duration since the previous read.  Used by bench.py's roofline. */
+int ic_prof_enable(int on);
+int ic_prof_kernel_count(void);
+const char* ic_prof_kernel_name(int kid);
+int ic_prof_read(int kid, int64_t* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

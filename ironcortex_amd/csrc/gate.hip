@@ -197,8 +197,8 @@ extern "C" int ic_gate_scores(const ic_gate_args* a, ic_stream_t stream) {
   IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "ic_gate_scores: d=%d unsupported", a->d);
   IC_REQUIRE(a->H && a->gain_ema && a->homeo, "ic_gate_scores: NULL pointer");
   IC_DISPATCH_DCH(a->d, {
-    hipLaunchKernelGGL(k_gate_scores<DCH>, dim3(ic_ceil_div(a->S * a->R, 4)), dim3(256), 0,
-                       (hipStream_t)stream, *a);
+    IC_TIMED(IC_KID_gate_scores, (hipStream_t)stream, hipLaunchKernelGGL(k_gate_scores<DCH>, dim3(ic_ceil_div(a->S * a->R, 4)), dim3(256), 0,
+                       (hipStream_t)stream, *a));
   });
   IC_LAUNCH_CHECK("ic_gate_scores");
   return IC_OK;
@@ -211,7 +211,7 @@ extern "C" int ic_gate_select(const ic_gate_args* a, ic_stream_t stream) {
   IC_REQUIRE(!a->force_io || (a->sensor_idx >= 0 && a->sensor_idx < a->R && a->motor_idx >= 0 &&
                               a->motor_idx < a->R),
              "ic_gate_select: io indices out of range");
-  hipLaunchKernelGGL(k_gate_select, dim3(a->S), dim3(256), 0, (hipStream_t)stream, *a);
+  IC_TIMED(IC_KID_gate_select, (hipStream_t)stream, hipLaunchKernelGGL(k_gate_select, dim3(a->S), dim3(256), 0, (hipStream_t)stream, *a));
   IC_LAUNCH_CHECK("ic_gate_select");
   return IC_OK;
 }
@@ -223,8 +223,8 @@ extern "C" int ic_kwta_bwd(const float* x, const float* gate, const float* gy, f
   IC_REQUIRE(!soft, "ic_kwta_bwd: soft mode is only differentiable inside ic_region_phase_bwd");
   const size_t n = (size_t)rows * d;
   if (n == 0) return IC_OK;
-  hipLaunchKernelGGL(k_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gy,
-                     gate, gx, n);
+  IC_TIMED(IC_KID_mul, (hipStream_t)stream, hipLaunchKernelGGL(k_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gy,
+                     gate, gx, n));
   IC_LAUNCH_CHECK("ic_kwta_bwd");
   return IC_OK;
 }
@@ -239,8 +239,8 @@ extern "C" int ic_rmsnorm_fwd(const float* x, const float* w, float* y, float* i
   IC_REQUIRE(x && w && y, "ic_rmsnorm_fwd: NULL pointer");
   IC_ROWS_CHECK("ic_rmsnorm_fwd");
   IC_DISPATCH_DCH(d, {
-    hipLaunchKernelGGL(k_rmsnorm_fwd<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, w, y, inv_s, rows, d, eps);
+    IC_TIMED(IC_KID_rmsnorm_fwd, (hipStream_t)stream, hipLaunchKernelGGL(k_rmsnorm_fwd<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, w, y, inv_s, rows, d, eps));
   });
   IC_LAUNCH_CHECK("ic_rmsnorm_fwd");
   return IC_OK;
@@ -251,8 +251,8 @@ extern "C" int ic_rmsnorm_bwd(const float* x, const float* w, const float* inv_s
   IC_REQUIRE(x && w && inv_s && gy && gx && gw_rows, "ic_rmsnorm_bwd: NULL pointer");
   IC_ROWS_CHECK("ic_rmsnorm_bwd");
   IC_DISPATCH_DCH(d, {
-    hipLaunchKernelGGL(k_rmsnorm_bwd<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, w, inv_s, gy, gx, gw_rows, rows, d);
+    IC_TIMED(IC_KID_rmsnorm_bwd, (hipStream_t)stream, hipLaunchKernelGGL(k_rmsnorm_bwd<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, w, inv_s, gy, gx, gw_rows, rows, d));
   });
   IC_LAUNCH_CHECK("ic_rmsnorm_bwd");
   return IC_OK;
@@ -262,8 +262,8 @@ extern "C" int ic_goodness_fwd(const float* H, float* g, int32_t rows, int32_t d
   IC_REQUIRE(H && g, "ic_goodness_fwd: NULL pointer");
   IC_ROWS_CHECK("ic_goodness_fwd");
   IC_DISPATCH_DCH(d, {
-    hipLaunchKernelGGL(k_goodness_fwd<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
-                       (hipStream_t)stream, H, g, rows, d);
+    IC_TIMED(IC_KID_goodness_fwd, (hipStream_t)stream, hipLaunchKernelGGL(k_goodness_fwd<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, H, g, rows, d));
   });
   IC_LAUNCH_CHECK("ic_goodness_fwd");
   return IC_OK;
@@ -274,8 +274,8 @@ extern "C" int ic_goodness_bwd(const float* H, const float* gg, float* gH, int32
   IC_REQUIRE(H && gg && gH, "ic_goodness_bwd: NULL pointer");
   IC_ROWS_CHECK("ic_goodness_bwd");
   IC_DISPATCH_DCH(d, {
-    hipLaunchKernelGGL(k_goodness_bwd<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
-                       (hipStream_t)stream, H, gg, gH, rows, d);
+    IC_TIMED(IC_KID_goodness_bwd, (hipStream_t)stream, hipLaunchKernelGGL(k_goodness_bwd<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, H, gg, gH, rows, d));
   });
   IC_LAUNCH_CHECK("ic_goodness_bwd");
   return IC_OK;

@@ -130,4 +130,46 @@ __device__ __forceinline__ void zero_frag(RowFrag<DCH>& f) {
     }                                              \
   } while (0)
 
+enum IcKid {
+  IC_KID_region_pro,
+  IC_KID_region_rkv,
+  IC_KID_region_out,
+  IC_KID_region_fin,
+  IC_KID_kwta_rows,
+  IC_KID_region_fin_bwd,
+  IC_KID_region_out_bwd,
+  IC_KID_region_mid_bwd,
+  IC_KID_region_rkv_bwd,
+  IC_KID_region_pro_bwd,
+  IC_KID_wgrad_region,
+  IC_KID_router_edge_fwd,
+  IC_KID_router_combine,
+  IC_KID_router_fwd,
+  IC_KID_router_comb_bwd,
+  IC_KID_router_mat_bwd,
+  IC_KID_router_gather_bwd,
+  IC_KID_wgrad_edge,
+  IC_KID_hebbian,
+  IC_KID_gate_scores,
+  IC_KID_gate_select,
+  IC_KID_mul,
+  IC_KID_rmsnorm_fwd,
+  IC_KID_rmsnorm_bwd,
+  IC_KID_goodness_fwd,
+  IC_KID_goodness_bwd,
+  IC_KID_COUNT
+};
+#define IC_KID_NAMES {"region_pro", "region_rkv", "region_out", "region_fin", "kwta_rows", "region_fin_bwd", "region_out_bwd", "region_mid_bwd", "region_rkv_bwd", "region_pro_bwd", "wgrad_region", "router_edge_fwd", "router_combine", "router_fwd", "router_comb_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_edge", "hebbian", "gate_scores", "gate_select", "mul", "rmsnorm_fwd", "rmsnorm_bwd", "goodness_fwd", "goodness_bwd"}
+
+// Optional live kernel timing with HIP events on the launch stream (ic_prof_* in the header).
+extern bool g_ic_prof_on;
+void ic_prof_begin(int kid, hipStream_t st);
+void ic_prof_end(int kid, hipStream_t st);
+#define IC_TIMED(kid, st, ...)                                  \
+  do {                                                          \
+    if (g_ic_prof_on) ic_prof_begin(kid, (hipStream_t)(st));    \
+    __VA_ARGS__;                                                \
+    if (g_ic_prof_on) ic_prof_end(kid, (hipStream_t)(st));      \
+  } while (0)
+
 static inline int ic_ceil_div(int a, int b) { return (a + b - 1) / b; }

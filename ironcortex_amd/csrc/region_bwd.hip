@@ -595,25 +595,25 @@ extern "C" int ic_region_phase_bwd(const ic_region_bwd_args* b, ic_stream_t stre
   const float oma = (float)(1.0 - a->pred_alpha);
   if (a->d <= 256) {
     constexpr int DCH = 1;
-    hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma);
-    hipLaunchKernelGGL((k_region_out_bwd<DCH, 8>), gmat, blk, 0, st, *b);
-    hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab);
-    hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 8>), gmat, blk, 0, st, *b);
-    hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    IC_TIMED(IC_KID_region_fin_bwd, st, hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma));
+    IC_TIMED(IC_KID_region_out_bwd, st, hipLaunchKernelGGL((k_region_out_bwd<DCH, 8>), gmat, blk, 0, st, *b));
+    IC_TIMED(IC_KID_region_mid_bwd, st, hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab));
+    IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 8>), gmat, blk, 0, st, *b));
+    IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else if (a->d <= 512) {
     constexpr int DCH = 2;
-    hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma);
-    hipLaunchKernelGGL((k_region_out_bwd<DCH, 2>), gmat, blk, 0, st, *b);
-    hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab);
-    hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 2>), gmat, blk, 0, st, *b);
-    hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    IC_TIMED(IC_KID_region_fin_bwd, st, hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma));
+    IC_TIMED(IC_KID_region_out_bwd, st, hipLaunchKernelGGL((k_region_out_bwd<DCH, 2>), gmat, blk, 0, st, *b));
+    IC_TIMED(IC_KID_region_mid_bwd, st, hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab));
+    IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 2>), gmat, blk, 0, st, *b));
+    IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else {
     constexpr int DCH = 4;
-    hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma);
-    hipLaunchKernelGGL((k_region_out_bwd<DCH, 2>), gmat, blk, 0, st, *b);
-    hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab);
-    hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 2>), gmat, blk, 0, st, *b);
-    hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    IC_TIMED(IC_KID_region_fin_bwd, st, hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma));
+    IC_TIMED(IC_KID_region_out_bwd, st, hipLaunchKernelGGL((k_region_out_bwd<DCH, 2>), gmat, blk, 0, st, *b));
+    IC_TIMED(IC_KID_region_mid_bwd, st, hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab));
+    IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 2>), gmat, blk, 0, st, *b));
+    IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   }
   IC_LAUNCH_CHECK("ic_region_phase_bwd");
   return IC_OK;
@@ -627,7 +627,7 @@ extern "C" int ic_region_wgrad(const ic_wgrad_region_args* a, ic_stream_t stream
              "ic_region_wgrad: NULL pointer");
   if (a->T == 0) return IC_OK;
   const dim3 grid(ic_ceil_div(a->d, 8), 4, a->R);
-  IC_DISPATCH_DCH(a->d, { hipLaunchKernelGGL(k_wgrad_region<DCH>, grid, dim3(256), 0, (hipStream_t)stream, *a); });
+  IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_wgrad_region, (hipStream_t)stream, hipLaunchKernelGGL(k_wgrad_region<DCH>, grid, dim3(256), 0, (hipStream_t)stream, *a)); });
   IC_LAUNCH_CHECK("ic_region_wgrad");
   return IC_OK;
 }

@@ -386,10 +386,10 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
   const dim3 gmat(ic_ceil_div(a->d, kRowsPerBlock), a->R);
   const float oma = (float)(1.0 - a->pred_alpha);
   IC_DISPATCH_DCH(a->d, {
-    hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a);
-    hipLaunchKernelGGL(k_region_rkv<DCH>, gmat, blk, 0, st, *a);
-    hipLaunchKernelGGL(k_region_out<DCH>, gmat, blk, 0, st, *a);
-    hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma);
+    IC_TIMED(IC_KID_region_pro, st, hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a));
+    IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL(k_region_rkv<DCH>, gmat, blk, 0, st, *a));
+    IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL(k_region_out<DCH>, gmat, blk, 0, st, *a));
+    IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma));
   });
   IC_LAUNCH_CHECK("ic_region_phase_fwd");
   return IC_OK;
@@ -402,8 +402,8 @@ extern "C" int ic_kwta_fwd(const float* x, float* y, float* gate, int32_t rows, 
   IC_REQUIRE(d >= 4 && d % 4 == 0 && d <= 1024, "ic_kwta_fwd: d=%d unsupported", d);
   if (rows == 0) return IC_OK;
   IC_DISPATCH_DCH(d, {
-    hipLaunchKernelGGL(k_kwta_rows<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, y, gate, rows, d, k, soft, temp);
+    IC_TIMED(IC_KID_kwta_rows, (hipStream_t)stream, hipLaunchKernelGGL(k_kwta_rows<DCH>, dim3(ic_ceil_div(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, gate, rows, d, k, soft, temp));
   });
   IC_LAUNCH_CHECK("ic_kwta_fwd");
   return IC_OK;

@@ -510,11 +510,11 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
   const int nsl = ic_ceil_div(a->d, kRowsPerBlock);
   if (a->flags & IC_RF_PRECISION) {
     IC_DISPATCH_DCH(a->d, {
-      hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R), dim3(256), 0, st, *a);
-      hipLaunchKernelGGL(k_router_combine<DCH>, dim3(ic_ceil_div(a->S * a->R, 4)), dim3(256), 0, st, *a);
+      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R), dim3(256), 0, st, *a));
+      IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<DCH>, dim3(ic_ceil_div(a->S * a->R, 4)), dim3(256), 0, st, *a));
     });
   } else {
-    IC_DISPATCH_DCH(a->d, { hipLaunchKernelGGL(k_router_fwd<DCH>, dim3(nsl, a->R), dim3(256), 0, st, *a); });
+    IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL(k_router_fwd<DCH>, dim3(nsl, a->R), dim3(256), 0, st, *a)); });
   }
   IC_LAUNCH_CHECK("ic_router_fwd");
   return IC_OK;
@@ -538,19 +538,19 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
   const int ny = a->E + ((a->flags & IC_RF_PRECISION) ? a->R : 0);
   if (a->d <= 256) {
     constexpr int DCH = 1;
-    hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b);
-    if (ny > 0) hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny), blk, 0, st, *b);
-    hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
+    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny), blk, 0, st, *b));
+    IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else if (a->d <= 512) {
     constexpr int DCH = 2;
-    hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b);
-    if (ny > 0) hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b);
-    hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
+    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b));
+    IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else {
     constexpr int DCH = 4;
-    hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b);
-    if (ny > 0) hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b);
-    hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab);
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
+    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b));
+    IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   }
   IC_LAUNCH_CHECK("ic_router_bwd");
   return IC_OK;
@@ -567,8 +567,8 @@ extern "C" int ic_router_wgrad(const ic_wgrad_edge_args* a, ic_stream_t stream) 
              "ic_router_wgrad: NULL pointer");
   IC_REQUIRE(a->which == 2 || (a->src && a->widx), "ic_router_wgrad: NULL edge table");
   IC_DISPATCH_DCH(a->d, {
-    hipLaunchKernelGGL(k_wgrad_edge<DCH>, dim3(ic_ceil_div(a->d, 8), ny), dim3(256), 0,
-                       (hipStream_t)stream, *a);
+    IC_TIMED(IC_KID_wgrad_edge, (hipStream_t)stream, hipLaunchKernelGGL(k_wgrad_edge<DCH>, dim3(ic_ceil_div(a->d, 8), ny), dim3(256), 0,
+                       (hipStream_t)stream, *a));
   });
   IC_LAUNCH_CHECK("ic_router_wgrad");
   return IC_OK;
@@ -581,8 +581,8 @@ extern "C" int ic_hebbian_rank1(float* W, const int32_t* dst_of_edge, const int3
   IC_REQUIRE(d >= 4 && d % 4 == 0 && d <= 1024, "ic_hebbian_rank1: d=%d unsupported", d);
   if (B <= 0 || E <= 0) return IC_OK;
   IC_DISPATCH_DCH(d, {
-    hipLaunchKernelGGL(k_hebbian<DCH>, dim3(ic_ceil_div(d, 8), E), dim3(256), 0, (hipStream_t)stream,
-                       W, dst_of_edge, src, widx, coef, H, B, R, d, E);
+    IC_TIMED(IC_KID_hebbian, (hipStream_t)stream, hipLaunchKernelGGL(k_hebbian<DCH>, dim3(ic_ceil_div(d, 8), E), dim3(256), 0, (hipStream_t)stream,
+                       W, dst_of_edge, src, widx, coef, H, B, R, d, E));
   });
   IC_LAUNCH_CHECK("ic_hebbian_rank1");
   return IC_OK;

@@ -237,6 +237,8 @@ class Router(nn.Module):
             ops.router_wgrad(tape, spec, tables, self._tape_S, 2, self._flat.stacked_grad("query_W"), tq)
             flags = torch.cat([tw, tk, tq]).bool().tolist()
             tw_l, tk_l, tq_l = flags[: self.nW], flags[self.nW: 2 * self.nW], flags[2 * self.nW:]
+            if any(tw_l):  # the reference stacks the queries of ALL regions (gate.py:293): zero grads, not None
+                tq_l = [True] * self.R
             self._flat.publish("key_W", tk_l)
             self._flat.publish("raw_P", tk_l)
             self._flat.publish("query_W", tq_l)

@@ -1,0 +1,96 @@
+"""Workspace and the small heads around the inner step (reference heads.py:12-119).
+Plain PyTorch on the GPU except the workspace sparsifier, which is the HIP KWTA kernel."""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .utils import KWTA, RMSNorm
+
+
+class Workspace(nn.Module):
+    """N slots of width d shared by all regions; writes are additive then KWTA'd (k = d//4)."""
+
+    def __init__(self, d: int, N_slots: int = 8):
+        super().__init__()
+        self.N = N_slots
+        self.norm = RMSNorm(d)
+        self.register_buffer("slots", torch.zeros(N_slots, d), persistent=False)
+
+    def read(self, keys: torch.Tensor) -> torch.Tensor:
+        return F.softmax(keys @ self.slots.T, dim=-1) @ self.slots
+
+    def write(self, delta_slots: torch.Tensor):
+        assert delta_slots.shape == self.slots.shape
+        self.slots = KWTA(self.slots + delta_slots, k=max(1, self.slots.shape[-1] // 4))
+
+
+class MLP(nn.Module):
+    def __init__(self, d_in: int, d_out: int, hidden: Optional[int] = None):
+        super().__init__()
+        hidden = hidden or max(d_in, d_out)
+        self.net = nn.Sequential(nn.Linear(d_in, hidden), nn.GELU(), nn.Linear(hidden, d_out))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class PlannerHead(nn.Module):
+    """(workspace, motor) -> (plan p, subgoal g)."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.mlp_p = MLP(d, d)
+        self.mlp_g = MLP(2 * d, d)
+
+    def forward(self, ws_state: torch.Tensor, motor_state: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        p = self.mlp_p(ws_state)
+        return p, self.mlp_g(torch.cat([p, ws_state], dim=-1))
+
+
+class CriticHead(nn.Module):
+    """Expected goodness gain of spending more compute."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.mlp = MLP(2 * d, 1)
+
+    def forward(self, ws_state: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+        return self.mlp(torch.cat([ws_state, g], dim=-1)).squeeze(-1)
+
+
+class VerifierHead(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.mlp = MLP(d, 1)
+
+    def forward(self, motor_state: torch.Tensor) -> torch.Tensor:
+        return torch.sigmoid(self.mlp(motor_state)).squeeze(-1)
+
+
+class RTDHead(nn.Module):
+    """Replaced-token detection logits [*, 2]."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.clf = nn.Linear(d, 2)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.clf(x)
+
+
+class TokenHead_MFS(nn.Module):
+    """Mixture of Kf linear facets gated by a softmax; returns (logits [V], aux)."""
+
+    def __init__(self, d: int, V: int, Kf: int = 8):
+        super().__init__()
+        self.V, self.Kf = V, Kf
+        self.gate = nn.Linear(d, Kf)
+        self.facets = nn.ModuleList([nn.Linear(d, V) for _ in range(Kf)])
+
+    def forward(self, x: torch.Tensor, targets: Optional[torch.Tensor] = None):
+        g = F.softmax(self.gate(x), dim=-1)
+        per_facet = torch.stack([f(x) for f in self.facets], dim=0)
+        logits = (g.unsqueeze(-1) * per_facet).sum(dim=0)
+        return logits, {"facet_balance": (g.mean() - 1.0 / self.Kf).pow(2)}

@@ -91,8 +91,9 @@ def lib():
             )
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ic_last_error.restype = ctypes.c_char_p
+        _lib.ic_prof_kernel_name.restype = ctypes.c_char_p
         for fn in FUNCTIONS:
-            if fn != "ic_last_error":
+            if fn not in ("ic_last_error", "ic_prof_kernel_name"):
                 getattr(_lib, fn).restype = ctypes.c_int
     return _lib
 
@@ -134,3 +135,19 @@ def stream_handle():
     import torch
 
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def prof_enable(on: bool) -> None:
+    lib().ic_prof_enable(ctypes.c_int(1 if on else 0))
+
+
+def prof_read() -> dict:
+    """{kernel name: (launches, total_ms)} since the previous read (synchronises)."""
+    out = {}
+    l = lib()
+    for kid in range(l.ic_prof_kernel_count()):
+        n, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+        check(l.ic_prof_read(ctypes.c_int(kid), ctypes.byref(n), ctypes.byref(ms)), "ic_prof_read")
+        if n.value:
+            out[l.ic_prof_kernel_name(ctypes.c_int(kid)).decode()] = (n.value, ms.value)
+    return out

@@ -1,0 +1,242 @@
+"""Token mixer that pools the focused positions into the sensor vector (off the §8 hot path;
+plain PyTorch on the GPU).  Parameter names follow reference iron_rope.py:100-374 and
+attention/adaptive_filter_attention.py so checkpoints load unchanged.
+
+Differences from the reference that do not change results:
+  * the Fourier relative bias b(p_q - p_k) is evaluated as a rank-2m feature product
+    (cos/sin addition theorem) instead of materialising a [B,T,T,m] tensor;
+  * no [1,1,max_T,max_T] mask buffer for the bidirectional case.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .constants import EPS_DIV, EPS_LOG, MAX_EXP
+from .utils import extract_spans, init_weights, masked_mean
+
+
+def make_freq_bank(m: int, d_coord: int, kind: str = "log", base: float = 10000.0, sigma: float = 1.0,
+                   device=None, dtype=None) -> torch.Tensor:
+    """[m, d_coord] frequency bank (iron_rope.py:16-37)."""
+    if kind == "log":
+        col = torch.logspace(math.log(1.0 / base), 0.0, steps=m, base=math.e, device=device, dtype=dtype)
+        return col.unsqueeze(1).repeat(1, d_coord)
+    if kind == "gaussian":
+        return torch.randn(m, d_coord, device=device, dtype=dtype) * sigma
+    raise ValueError(f"Unknown freq kind: {kind}")
+
+
+def sincos(W: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    theta = p @ W.T
+    return torch.cat([torch.sin(theta), torch.cos(theta)], dim=-1)
+
+
+def rope_rotate_pairs(x: torch.Tensor, cos_th: torch.Tensor, sin_th: torch.Tensor, m_pairs: int) -> torch.Tensor:
+    """Rotate channel pairs (2j, 2j+1), j < m_pairs (iron_rope.py:49-66)."""
+    if m_pairs <= 0:
+        return x
+    head, tail = x[..., : 2 * m_pairs], x[..., 2 * m_pairs:]
+    even, odd = head[..., 0::2], head[..., 1::2]
+    rot = torch.stack((even * cos_th - odd * sin_th, even * sin_th + odd * cos_th), dim=-1)
+    return torch.cat([rot.flatten(-2), tail], dim=-1)
+
+
+def relative_fourier_bias(p_q, p_k, W, beta_cos, beta_sin, scale: float = 1.0) -> torch.Tensor:
+    """b[q,k] = scale * sum_m cos(S)beta_cos + sin(S)beta_sin, S = (p_q - p_k) W^T
+    (iron_rope.py:69-97), evaluated without the [B,Tq,Tk,m] intermediate."""
+    if W.shape[1] != p_q.shape[-1]:  # the reference's einsum broadcasts a size-1 coordinate axis
+        W = W.expand(W.shape[0], p_q.shape[-1])
+    aq, ak = p_q @ W.T, p_k @ W.T  # [B,T,m]
+    cq, sq, ck, sk = torch.cos(aq), torch.sin(aq), torch.cos(ak), torch.sin(ak)
+    if beta_cos.dim() == 2:  # headwise [H,m]
+        bc, bs = beta_cos[None, :, None, :], beta_sin[None, :, None, :]
+        cq, sq = cq.unsqueeze(1), sq.unsqueeze(1)
+        left = torch.cat([cq * bc + sq * bs, sq * bc - cq * bs], dim=-1)
+        right = torch.cat([ck, sk], dim=-1).unsqueeze(1)
+        return scale * (left @ right.transpose(-2, -1))
+    left = torch.cat([cq * beta_cos + sq * beta_sin, sq * beta_cos - cq * beta_sin], dim=-1)
+    right = torch.cat([ck, sk], dim=-1)
+    return (scale * (left @ right.transpose(-2, -1))).unsqueeze(1)
+
+
+class IronRoPESelfAttention(nn.Module):
+    """Bidirectional self-attention with rotary q/k and a Fourier relative bias
+    (iron_rope.py:100-251).  Only positions in update_mask are changed."""
+
+    def __init__(self, n_embd: int, n_head: int, block_size: int, use_iron_rope: bool = True,
+                 rope_m: int = 64, rope_coord_dim: int = 1, rope_kind: str = "log", rope_base: float = 10000.0,
+                 rope_sigma: float = 1.0, use_fourier_bias: bool = True, fb_m: int = 32, fb_coord_dim: int = 1,
+                 fb_kind: str = "gaussian", fb_base: float = 10000.0, fb_sigma: float = 1.0,
+                 fb_headwise: bool = False, attn_pdrop: float = 0.0, resid_pdrop: float = 0.0,
+                 causal: bool = False):
+        super().__init__()
+        assert n_embd % n_head == 0
+        self.n_head, self.head_dim = n_head, n_embd // n_head
+        self.block_size, self.causal = block_size, causal
+        self.c_attn = nn.Linear(n_embd, 3 * n_embd)
+        self.c_proj = nn.Linear(n_embd, n_embd)
+        self.adrop, self.rdrop = nn.Dropout(attn_pdrop), nn.Dropout(resid_pdrop)
+        self.register_buffer("last_attn_energy", torch.tensor(0.0), persistent=False)
+        self.use_rope = use_iron_rope
+        self.rope_m = min(self.head_dim // 2, rope_m) if use_iron_rope else 0
+        if self.rope_m > 0:
+            self.register_buffer("W_rope", make_freq_bank(self.rope_m, rope_coord_dim, rope_kind, rope_base, rope_sigma))
+        self.use_fb = use_fourier_bias
+        self.fb_m = fb_m if use_fourier_bias else 0
+        if self.fb_m > 0:
+            self.register_buffer("W_fb", make_freq_bank(self.fb_m, fb_coord_dim, fb_kind, fb_base, fb_sigma))
+            shape = (n_head, self.fb_m) if fb_headwise else (self.fb_m,)
+            self.beta_cos = nn.Parameter(torch.zeros(shape))
+            self.beta_sin = nn.Parameter(torch.zeros(shape))
+            nn.init.normal_(self.beta_cos, std=0.01)
+            nn.init.normal_(self.beta_sin, std=0.01)
+            self.fb_scale = 1.0 / math.sqrt(self.fb_m)
+
+    def forward(self, x, coords=None, update_mask=None, context_mask=None, dropout: bool = True):
+        B, T, C = x.shape
+        assert T <= self.block_size
+        if coords is None:
+            coords = torch.arange(T, device=x.device, dtype=torch.float32).view(1, T, 1).expand(B, T, 1)
+        elif coords.dim() == 2:
+            coords = coords.unsqueeze(0).expand(B, -1, -1)
+        q, k, v = self.c_attn(x).split(C, dim=2)
+        shp = (B, T, self.n_head, self.head_dim)
+        q, k, v = (t.view(shp).transpose(1, 2) for t in (q, k, v))
+        if self.rope_m > 0:
+            theta = coords @ self.W_rope.T
+            c, s = torch.cos(theta).unsqueeze(1), torch.sin(theta).unsqueeze(1)
+            q, k = rope_rotate_pairs(q, c, s, self.rope_m), rope_rotate_pairs(k, c, s, self.rope_m)
+        att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(self.head_dim))
+        if self.fb_m > 0:
+            att = att + relative_fourier_bias(coords, coords, self.W_fb, self.beta_cos, self.beta_sin, self.fb_scale)
+        if self.causal:
+            keep = torch.ones(T, T, dtype=torch.bool, device=x.device).tril()
+            att = att.masked_fill(~keep, float("-inf"))
+        if context_mask is not None:
+            att = att.masked_fill(~context_mask[:, None, None, :].to(torch.bool), float("-inf"))
+        att = F.softmax(att, dim=-1)
+        self.last_attn_energy = (-(att + EPS_LOG).log().mean()).detach()
+        if dropout:
+            att = self.adrop(att)
+        y = self.c_proj((att @ v).transpose(1, 2).contiguous().view(B, T, C))
+        if dropout:
+            y = self.rdrop(y)
+        if update_mask is not None:
+            return x + y * update_mask.unsqueeze(-1).to(y.dtype)
+        return x + y
+
+
+class AdaptiveFilterAttention(nn.Module):
+    """Dot-product attention times exp(-alpha |lag| dt) (adaptive_filter_attention.py:8-127)."""
+
+    def __init__(self, d_model: int, n_head: int, dt: float = 1.0, alpha: float = 0.0, *,
+                 debug_exact: bool = False, exact_threshold: int = 64):
+        super().__init__()
+        assert d_model % n_head == 0
+        self.d_model, self.n_head, self.head_dim = d_model, n_head, d_model // n_head
+        self.scale = self.head_dim ** -0.5
+        self.dt = dt
+        self.alpha = nn.Parameter(torch.tensor(alpha))
+        self.debug_exact, self.exact_threshold = debug_exact, exact_threshold
+        self.q_proj, self.k_proj = nn.Linear(d_model, d_model), nn.Linear(d_model, d_model)
+        self.v_proj, self.out_proj = nn.Linear(d_model, d_model), nn.Linear(d_model, d_model)
+        self.register_buffer("last_attn_energy", torch.tensor(0.0), persistent=False)
+        self.register_buffer("last_kernel_norm", torch.tensor(0.0), persistent=False)
+        self.last_attn_entropy = torch.tensor(0.0)
+
+    def _attend(self, q, k, v, mask):
+        T = q.size(-2)
+        idx = torch.arange(T, device=q.device, dtype=torch.float32)
+        lag = (idx.view(T, 1) - idx.view(1, T)).abs()
+        decay = torch.exp(-self.alpha * lag * self.dt)  # gradient reaches alpha exactly as via the gather
+        self.last_kernel_norm = decay.norm().detach()
+        scores = (q @ k.transpose(-2, -1)) * self.scale * decay
+        if mask is not None:
+            if mask.dim() == 3:
+                mask = mask.unsqueeze(1)
+            scores = scores.masked_fill(mask == 0, -MAX_EXP)
+        attn = F.softmax(scores, dim=-1)
+        if mask is not None:
+            attn = attn * mask
+            attn = attn / attn.sum(dim=-1, keepdim=True).clamp_min(EPS_DIV)
+        logp = (attn + EPS_LOG).log()
+        self.last_attn_energy = (-logp.mean()).detach()
+        self.last_attn_entropy = (-(logp * attn).sum(dim=-1).mean()).detach()
+        return attn @ v
+
+    def forward(self, x, mask=None):
+        B, T, _ = x.shape
+        shp = (B, T, self.n_head, self.head_dim)
+        q, k, v = (p(x).view(shp).transpose(1, 2) for p in (self.q_proj, self.k_proj, self.v_proj))
+        out = self._attend(q, k, v, mask)  # the reference's kernel path is the exact path (:89-98)
+        return self.out_proj(out.transpose(1, 2).contiguous().view(B, T, self.d_model))
+
+    def telemetry(self) -> dict:
+        return {"alpha": float(self.alpha.detach()), "kernel_norm": float(self.last_kernel_norm),
+                "attn_entropy_mean": float(self.last_attn_entropy)}
+
+
+class LocalTokenMixer(nn.Module):
+    """Anchor tokens + one attention block; returns the mean of the focused positions
+    (iron_rope.py:254-374)."""
+
+    def __init__(self, d: int, n_head: int = 4, block_size: int = 8192, m_tok: int = 64, use_afa: bool = False):
+        super().__init__()
+        if use_afa:
+            self.attn = AdaptiveFilterAttention(d_model=d, n_head=n_head)
+            self.use_anchors = False
+            self.register_parameter("anch_embed", None)
+        else:
+            self.attn = IronRoPESelfAttention(n_embd=d, n_head=n_head, block_size=block_size, use_iron_rope=True,
+                                              rope_m=m_tok, rope_coord_dim=2, use_fourier_bias=True, fb_m=32,
+                                              fb_coord_dim=1, causal=False)
+            self.use_anchors = True
+            self.anch_embed = nn.Parameter(torch.randn(3, d) * 0.02)  # centre / span start / span end
+        self.register_buffer("last_energy", torch.tensor(0.0), persistent=False)
+        self.apply(init_weights)
+
+    @torch.no_grad()
+    def build_anchors(self, T: int, focus_mask: torch.Tensor, strides=(128, 32)) -> List[Tuple[int, int]]:
+        if not self.use_anchors:
+            return []
+        anchors = [(i, 0) for S in strides for i in range(S // 2, T, S)]
+        if focus_mask is not None:
+            for start, end in extract_spans(focus_mask):  # one host read of the focus bits
+                anchors += [(start, 1), (max(start, end - 1), 2)]
+        return anchors
+
+    def forward(self, tok_emb, pos_coords, focus_mask, ws_slots: Optional[torch.Tensor] = None,
+                use_dropout: bool = True) -> torch.Tensor:
+        B, T, d = tok_emb.shape
+        dev = tok_emb.device
+        if not self.use_anchors:
+            pooled = masked_mean(self.attn(tok_emb), focus_mask)
+            self.last_energy = self.attn.last_attn_energy.detach()
+            return pooled
+        rows, n_max = [], 0
+        for b in range(B):
+            anchors = self.build_anchors(T, focus_mask[b])
+            rows.append(anchors)
+            n_max = max(n_max, len(anchors))
+        Ta = T + n_max
+        X = torch.zeros(B, Ta, d, device=dev)
+        C = torch.zeros(B, Ta, 2, device=dev)
+        UM = torch.zeros(B, Ta, dtype=torch.bool, device=dev)
+        X[:, :T], C[:, :T], UM[:, :T] = tok_emb, pos_coords, focus_mask
+        for b, anchors in enumerate(rows):
+            if anchors:
+                a_idx = torch.tensor([a[0] for a in anchors], dtype=torch.long, device=dev)
+                a_kind = torch.tensor([a[1] for a in anchors], dtype=torch.long, device=dev)
+                n = len(anchors)
+                X[b, T:T + n] = self.anch_embed[a_kind]
+                pos = a_idx.to(torch.float32)
+                C[b, T:T + n] = torch.stack([pos, pos / (T + EPS_DIV)], dim=-1)
+        Y = self.attn(X, coords=C, update_mask=UM, context_mask=None, dropout=use_dropout)
+        pooled = masked_mean(Y[:, :T, :], focus_mask)
+        self.last_energy = self.attn.last_attn_energy.detach()
+        return pooled

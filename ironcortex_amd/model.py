@@ -1,0 +1,286 @@
+"""CortexReasoner: the reference's container and inner loop (model.py:33-503) with the
+gate -> router -> region-cell phase executed by the HIP library.
+
+Same constructor, same method signatures and return tuples, same state_dict keys.  Inside
+forward_inner_step the three hot blocks are three fused calls (Gate.score_select,
+Router.route, RegionBank.phase) instead of a Python loop over regions.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import CortexConfig
+from .constants import EPS_DIV
+from .energy import EnergyVerifierHead
+from .gate import Gate, Router
+from .heads import CriticHead, PlannerHead, RTDHead, TokenHead_MFS, Workspace
+from .hip import ops
+from .mixer import LocalTokenMixer
+from .region import RegionBank, RWKVRegionCell
+from .sdr import SparseTokenEncoder
+from .utils import (RegionFFState, RMSNorm, context_logprob, goodness, init_weights, schedule_burst,
+                    should_halt, uncertainty_from_logits)
+
+
+class CortexReasoner(nn.Module):
+    def __init__(self, neighbor_indices: List[List[int]], reg_coords: torch.Tensor, io_idxs: Dict[str, int],
+                 cfg: CortexConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.R, self.d, self.V = cfg.R, cfg.d, cfg.V
+        self.io_idxs = io_idxs
+        self.neighbors = neighbor_indices
+        self.register_buffer("reg_coords", reg_coords.to(torch.float32))
+        self.embed = SparseTokenEncoder(self.V, self.d, cfg.sdr_k)
+        self._coord = ops.GradCoordinator()
+        self.regions = nn.ModuleList([
+            RWKVRegionCell(
+                self.d, init_decay=cfg.init_decay,
+                enable_adaptive_filter_dynamics=cfg.enable_adaptive_filter_dynamics,
+                enable_radial_tangential_updates=cfg.enable_radial_tangential_updates,
+                afd_noise_mode=cfg.afd_noise_mode, use_predictive_trace=cfg.use_predictive_trace,
+                kwta_k=cfg.kwta_k, kwta_k_start=cfg.kwta_k_start, kwta_k_schedule=cfg.kwta_k_schedule,
+                kwta_soft_mode=cfg.kwta_soft_mode, kwta_soft_temp=cfg.kwta_soft_temp,
+                disable_kwta=cfg.disable_kwta_during_gating, _shared_bank=True)
+            for _ in range(self.R)])
+        # all cells are windows onto one stacked bank (plain attribute: not a submodule)
+        object.__setattr__(self, "bank", RegionBank(list(self.regions), io_idxs["sensor"], io_idxs["motor"],
+                                                    coord=self._coord))
+        self.gate = Gate(self.R, self.neighbors, io_idxs)
+        self.router = Router(self.neighbors, self.d, self.R,
+                             enable_precision_routed_messages=cfg.enable_precision_routed_messages,
+                             vectorized=cfg.router_vectorized, edge_transform_mode=cfg.edge_transform_mode,
+                             _coord=self._coord)
+        self.rtdd = RTDHead(self.d)
+        self.lm_head = TokenHead_MFS(self.d, self.V, Kf=8)
+        self.region_heads = nn.ModuleList([nn.Linear(self.d, self.V) for _ in range(self.R)])
+        self.work = Workspace(self.d, N_slots=8)
+        if cfg.train_deterministic_inner_loop:
+            self.plan = None
+            self.critic = None
+        else:
+            self.plan = PlannerHead(self.d)
+            self.critic = CriticHead(self.d)
+        self.verify = None
+        self.verify_state = None
+        if cfg.enable_energy_verifier:
+            aux_dim = 3 if cfg.enable_ff_energy_alignment else 0
+            self.verify = EnergyVerifierHead(self.d, self.V, hidden=self.d, aux_dim=aux_dim)
+            if cfg.enable_ff_energy_alignment:
+                self.verify_state = RegionFFState()
+                self.register_buffer("E_pos_mean", torch.tensor(0.0), persistent=False)
+                self.register_buffer("E_neg_mean", torch.tensor(0.0), persistent=False)
+        self.local_mix = LocalTokenMixer(self.d, n_head=4, block_size=cfg.max_T, m_tok=64,
+                                         use_afa=cfg.enable_afa_attention)
+        self.norm_in = RMSNorm(self.d)
+        self.reg_ff = nn.ModuleList([RegionFFState() for _ in range(self.R)])
+        self.apply(init_weights)
+        self._profile_times = {"attention": 0.0, "routing": 0.0, "region": 0.0, "total": 0.0}
+        self._profile_mem = {"attention": 0, "routing": 0, "region": 0}
+        self._sensor_cache = None
+        self.counters = {"inner_steps": 0}
+
+    # ------------------------------------------------------------------ plumbing
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self.bank.to_device()
+        return self
+
+    def detach_state(self) -> None:
+        if hasattr(self, "work"):
+            self.work.slots = self.work.slots.detach()
+        self.bank.detach_state()
+
+    def telemetry(self) -> dict:
+        b = self.bank
+        var = b.var[0]
+        reg_stats = [{"state_var": v, "state_prec": p, "surprise_ema": s} for v, p, s in zip(
+            var.mean(-1).tolist(), (var + EPS_DIV).reciprocal().mean(-1).tolist(), b.surprise[0].tolist())]
+        mean = lambda k: float(sum(r[k] for r in reg_stats) / max(1, len(reg_stats)))
+        attn = getattr(self.local_mix, "attn", None)
+        afa = attn.telemetry() if attn is not None and hasattr(attn, "telemetry") else None
+        if self.cfg.enable_precision_routed_messages:
+            self.router._weight_stats()
+        out = {"regions": reg_stats, "routing_weight_mean": self.router.last_weight_mean,
+               "router_weight_entropy": self.router.last_weight_entropy, "state_var_mean": mean("state_var"),
+               "state_prec_mean": mean("state_prec"), "surprise_ema": mean("surprise_ema"),
+               "attn_entropy_mean": afa.get("attn_entropy_mean", 0.0) if afa else 0.0}
+        if self.verify_state is not None:
+            out.update(E_pos_mean=float(self.E_pos_mean.detach()), E_neg_mean=float(self.E_neg_mean.detach()),
+                       verifier_tau=float(self.verify_state.tau.detach()))
+        if afa is not None:
+            out["afa"] = afa
+        return out
+
+    def report_profile(self) -> None:
+        total = self._profile_times.get("total", 0.0)
+        if total <= 0:
+            return
+        pct = {k: self._profile_times[k] / total * 100.0 for k in ("attention", "routing", "region")}
+        mb = {k: v / 1e6 for k, v in self._profile_mem.items()}
+        print(f"profile time%%: attn={pct['attention']:.1f} rout={pct['routing']:.1f} reg={pct['region']:.1f}; "
+              f"memMB: attn={mb['attention']:.1f} rout={mb['routing']:.1f} reg={mb['region']:.1f}")
+        for k in self._profile_times:
+            self._profile_times[k] = 0.0
+        for k in self._profile_mem:
+            self._profile_mem[k] = 0
+
+    def region_input(self, r: int, x_sensor: torch.Tensor, msg: torch.Tensor) -> torch.Tensor:
+        x = msg + x_sensor if r in (self.io_idxs["sensor"], self.io_idxs["motor"]) else msg
+        return self.norm_in(x)
+
+    def _clock(self) -> float:
+        """Profile clock; the stream is drained first so the timers measure run time, not
+        launch time (the reference reads perf_counter without a sync)."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
+    # ------------------------------------------------------------------ sensor vector
+    def sensor_vector(self, tokens: torch.Tensor, focus_map: torch.Tensor) -> torch.Tensor:
+        """model.py:231-247.  The mixer sees only (tokens, focus), never the region state, and
+        its dropouts have p = 0, so within one reasoning loop the result is reused."""
+        key = (tokens.data_ptr(), tokens._version, focus_map.data_ptr(), focus_map._version,
+               torch.is_grad_enabled(), next(self.local_mix.parameters())._version)
+        if self._sensor_cache is not None and self._sensor_cache[0] == key:
+            return self._sensor_cache[1]
+        T, dev = tokens.shape[0], tokens.device
+        tok_emb = self.embed(tokens).unsqueeze(0)
+        idx = torch.arange(T, device=dev, dtype=torch.float32)
+        pos = torch.stack([idx, idx / (T + EPS_DIV)], dim=-1).unsqueeze(0)
+        vec = self.local_mix(tok_emb, pos, focus_map.unsqueeze(0), ws_slots=None, use_dropout=self.cfg.ff_dropout)[0]
+        self._sensor_cache = (key, vec, tokens, focus_map)
+        return vec
+
+    # ------------------------------------------------------------------ one inner micro-step
+    def forward_inner_step(self, tokens: torch.Tensor, step_k: int, focus_map: torch.Tensor, H_prev: torch.Tensor,
+                           reg_mask_prev: torch.Tensor, u_mean: float, burst_extra_k: int):
+        """gate -> route -> active region updates -> heads (model.py:206-321)."""
+        dev = H_prev.device
+        prof = self.cfg.profile
+        if prof:
+            t_total = self._clock()
+        sensor_vec = self.sensor_vector(tokens, focus_map)
+        if prof:
+            t0 = self._clock()
+            self._profile_times["attention"] += t0 - t_total
+        # 1) gate: scores + neighbour-suppressed top-k on the device
+        focus_any = focus_map.any().to(torch.uint8).reshape(1) if focus_map.numel() > 0 else torch.ones(1, dtype=torch.uint8, device=dev)
+        _, mask = self.gate.score_select(H_prev.unsqueeze(0), focus_any, u_mean, self.cfg.k_active, burst_extra_k)
+        # 2) router messages from the previously active regions
+        if prof:
+            t0 = self._clock()
+        M = self.router.route(H_prev.unsqueeze(0), reg_mask_prev.to(torch.uint8).reshape(1, -1), self.reg_coords)
+        if prof:
+            t1 = self._clock()
+            self._profile_times["routing"] += t1 - t0
+        # 3) all regions in one fused phase (active: step; inactive: trace + skip)
+        step_pos = float(step_k) / float(max(1, self.cfg.K_inner - 1))
+        H_cur = self.bank.phase(M, sensor_vec.unsqueeze(0), self.norm_in.weight, mask, step_pos)[0]
+        if prof:
+            t2 = self._clock()
+            self._profile_times["region"] += t2 - t1
+            self._profile_times["total"] += t2 - t_total
+        self.counters["inner_steps"] += 1
+        # 4) heads on motor & workspace
+        reg_mask = mask[0].bool()
+        active = reg_mask.nonzero(as_tuple=False).squeeze(-1)
+        active_list = active.tolist()  # the one host sync of the step
+        motor = self.io_idxs["motor"]
+        motor_state = H_cur[motor]
+        delta = torch.zeros_like(self.work.slots)
+        n_write = min(len(active_list), delta.shape[0])
+        if n_write > 0:
+            delta[:n_write] = H_cur[active[:n_write]]
+            self.work.write(delta)
+            ws_state = self.work.slots.mean(dim=0)
+        else:
+            ws_state = torch.zeros(self.d, device=dev)
+        motor_logits, _ = self.lm_head(motor_state)
+        parts = [motor_logits] + [self.region_heads[r](H_cur[r]) for r in active_list if r != motor]
+        logits = torch.stack(parts, dim=0).mean(dim=0)
+        rtd_logits = self.rtdd(motor_state)
+        return H_cur, reg_mask, logits, rtd_logits, ws_state, motor_state
+
+    @torch.no_grad()
+    def zeros_state(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        return torch.zeros(self.R, self.d, device=device), torch.zeros(self.R, dtype=torch.bool, device=device)
+
+    def _verify_aux(self, device) -> Optional[torch.Tensor]:
+        if not self.cfg.enable_ff_energy_alignment:
+            return None
+        ent = getattr(self.local_mix.attn, "last_attn_entropy", torch.tensor(0.0, device=device))
+        return torch.stack([self.local_mix.last_energy.detach().to(device),
+                            self.bank.surprise[0].mean().to(device), ent.detach().to(device)])
+
+    # ------------------------------------------------------------------ reasoning loop
+    def reasoning_loop(self, tokens: torch.Tensor, K_inner: int, focus_map: torch.Tensor,
+                       reg_mask_prev: torch.Tensor, H_prev: torch.Tensor):
+        """plan -> critic -> gate; branch; verify; halt (model.py:329-460)."""
+        dev = H_prev.device
+        self._sensor_cache = None
+        last_logits = torch.zeros(self.V, device=dev)
+        traces: List[torch.Tensor] = []
+        if self.cfg.train_deterministic_inner_loop:
+            for k in range(K_inner):
+                u_mean = uncertainty_from_logits(last_logits) if k > 0 else 0.0
+                self.gate.value_bias = 0.0
+                H_cur, reg_mask, logits, _r, _w, _m = self.forward_inner_step(
+                    tokens, k, focus_map, H_prev, reg_mask_prev, u_mean, 0)
+                traces.append(H_cur.clone())
+                H_prev, reg_mask_prev, last_logits = H_cur, reg_mask, logits
+            return H_cur, reg_mask, last_logits, traces
+
+        branches = [(self.work.slots.clone(), reg_mask_prev.clone(), H_prev.clone()) for _ in range(self.cfg.B_br)]
+        scores = [torch.tensor(-1e9, device=dev) for _ in range(self.cfg.B_br)]
+        motor = self.io_idxs["motor"]
+        for k in range(K_inner):
+            u_mean = uncertainty_from_logits(last_logits) if k > 0 else 0.0
+            on = reg_mask_prev.to(H_prev.dtype)
+            n_on = on.sum()
+            # mean of the previously active rows (zeros when none): no host sync needed
+            ws_prev = (H_prev * on.unsqueeze(-1)).sum(0) / n_on.clamp_min(1.0)
+            _p, g = self.plan(ws_prev, H_prev[motor])
+            v_hat = float(self.critic(ws_prev, g).item())
+            self.gate.value_bias = v_hat
+            burst = schedule_burst(u_mean, v_hat, self.R)
+            for b in range(self.cfg.B_br):
+                self.work.slots = branches[b][0].clone()
+                H_b, m_b = branches[b][2].clone(), branches[b][1].clone()
+                H_cur, reg_mask, logits, _rtd, _ws, motor_state = self.forward_inner_step(
+                    tokens, k, focus_map, H_b, m_b, u_mean, burst)
+                ver_energy = self.verify(motor_state, F.softmax(logits.detach(), dim=-1), aux=self._verify_aux(dev))
+                delta_g = goodness(H_cur) - goodness(H_b)
+                scores[b] = 0.6 * delta_g + 0.2 * (-ver_energy) + 0.2 * context_logprob(logits)
+                branches[b] = (self.work.slots.clone(), reg_mask.clone(), H_cur.clone())
+                last_logits = logits
+            top = torch.topk(torch.stack(scores), k=min(self.cfg.B_br, 2)).indices.tolist()
+            branches = [branches[i] for i in top]
+            scores = [scores[i] for i in top]
+            traces.append(branches[0][2].clone())
+            if should_halt(scores, u_mean, k, K_inner):
+                break
+            self.work.slots, reg_mask_prev, H_prev = branches[0]
+        best = int(torch.stack(scores).argmax().item())
+        self.work.slots, reg_mask, H_cur = branches[best]
+        return H_cur, reg_mask, last_logits, traces
+
+    def reasoning_loop_batch(self, tokens_batch: torch.Tensor, K_inner: int, focus_batch: torch.Tensor):
+        """Sequential over the batch, region fast-weight state carried from one sample to the
+        next (detached), exactly as the reference (model.py:462-503)."""
+        dev = tokens_batch.device
+        H_l, M_l, L_l, T_l, E_l, A_l = [], [], [], [], [], []
+        for b in range(tokens_batch.shape[0]):
+            self.detach_state()
+            H_prev, mask_prev = self.zeros_state(dev)
+            H_cur, reg_mask, logits, traces = self.reasoning_loop(tokens_batch[b], K_inner, focus_batch[b], mask_prev, H_prev)
+            H_l.append(H_cur); M_l.append(reg_mask); L_l.append(logits); T_l.append(traces)
+            E_l.append(self.local_mix.last_energy.detach())
+            ent = getattr(getattr(self.local_mix, "attn", None), "last_attn_entropy", torch.tensor(0.0))
+            A_l.append(ent.detach().to(dev))
+        return (torch.stack(H_l), torch.stack(M_l), torch.stack(L_l), T_l, torch.stack(E_l), torch.stack(A_l))

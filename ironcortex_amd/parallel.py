@@ -1,0 +1,83 @@
+"""Data parallelism for train_step: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference has no distributed code; the forward-forward step shards by batch
+with ONE exchange per step:
+  * gradients: every parameter's gradient is packed into flat fp32 buckets (the hot-path
+    arenas are already flat) and all-reduced (sum / world); a parameter whose gradient is None
+    on this rank but not on another receives the averaged gradient, one that is None everywhere
+    stays None so AdamW skips it exactly as in a single-process run;
+  * batch statistics that drive buffer updates (goodness gains, tau targets, verifier energy
+    means) are averaged, the homeostasis mask is OR-ed;
+  * the positive-stream states needed by the Hebbian edge nudges are all-gathered (B*R*d
+    floats), so every rank applies the same update and replicas never diverge.
+Region fast-weight state stays rank-local (it is not checkpointed state).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, bucket_mb: int = 64):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.bucket_elems = bucket_mb * (1 << 20) // 4
+
+    # ------------------------------------------------------------------ small helpers
+    def mean(self, t: torch.Tensor) -> torch.Tensor:
+        out = t.detach().clone().contiguous()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out / self.world
+
+    def any(self, t: torch.Tensor) -> torch.Tensor:
+        out = t.to(torch.int32).contiguous()
+        dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.group)
+        return out.bool()
+
+    def gather(self, t: torch.Tensor) -> torch.Tensor:
+        """Concatenate equal-shaped per-rank tensors along dim 0 (rank order)."""
+        t = t.detach().contiguous()
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t, group=self.group)
+        return torch.cat(parts, dim=0)
+
+    def broadcast_module(self, module: torch.nn.Module, src: int = 0) -> None:
+        """Make replicas identical at start (parameters and persistent buffers)."""
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src=src, group=self.group)
+
+    # ------------------------------------------------------------------ gradients
+    def sync_grads(self, module: torch.nn.Module) -> None:
+        params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            return
+        dev = params[0].device
+        have = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MAX, group=self.group)
+        have_l = have.tolist()
+        live = [p for p, h in zip(params, have_l) if h]
+        for p in live:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        # pack into buckets, one all-reduce per bucket
+        i = 0
+        while i < len(live):
+            j, n = i, 0
+            while j < len(live) and (n == 0 or n + live[j].numel() <= self.bucket_elems):
+                n += live[j].numel()
+                j += 1
+            flat = torch.cat([p.grad.reshape(-1) for p in live[i:j]])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+            off = 0
+            for p in live[i:j]:
+                k = p.numel()
+                p.grad.copy_(flat[off:off + k].view_as(p.grad))
+                off += k
+            i = j

@@ -1,0 +1,186 @@
+"""Forward-forward train_step with the reference's signature and 15-key metrics
+(reference training.py:22-273).  The per-region Python loops with .item() syncs are replaced
+by batched device ops; the update order is the reference's: backward -> grad norm -> Hebbian
+edge nudges -> homeostasis -> optimizer.step."""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from .constants import EPS_DIV
+from .corruptions import corrupt
+from .energy import ff_energy_loss
+from .hip import ops
+from .model import CortexReasoner
+
+
+@dataclass
+class LossWeights:
+    ff: float = 1.0
+    rtd: float = 0.5
+    denoise: float = 1.0
+    critic: float = 0.25
+    verify: float = 0.25
+    facet: float = 1e-3
+
+
+def make_negatives(clean_tokens: torch.Tensor, V: int):
+    """Corrupt every sequence (training.py:70-89).  Random draws happen on the CPU generator in
+    the reference's order; only the results travel to the device."""
+    dev = clean_tokens.device
+    host = clean_tokens.cpu()
+    neg, focus, targets, masks, real = [], [], [], [], []
+    for b in range(host.shape[0]):
+        mode = random.choices(["RTD", "SPAN", "BLOCK"], weights=[0.5, 0.3, 0.2])[0]
+        x_neg, is_real, fm, d_t, d_m = corrupt(host[b], V, mode)
+        neg.append(x_neg); focus.append(fm); targets.append(d_t); masks.append(d_m)
+        real.append(bool(is_real.all()))
+    return (torch.stack(neg).to(dev), torch.stack(focus).to(dev), torch.stack(targets), torch.stack(masks), real)
+
+
+def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_tokens: torch.Tensor,
+               λ: LossWeights, device: torch.device, dp=None) -> Dict[str, float]:
+    """One FF training step.  dp (ironcortex_amd.parallel.DataParallel, optional) shards the batch
+    over ranks: clean_tokens is then this rank's shard and the one exchange per step happens
+    between backward and the updates."""
+    model.train()
+    model.detach_state()
+    cfg = model.cfg
+    B, T = clean_tokens.shape
+    optimizer.zero_grad()
+    step = getattr(model, "_train_step", 0) + 1
+    model._train_step = step
+    for reg in model.regions:
+        reg.global_step = step
+    lam_s = 0.0
+    if cfg.enable_ff_energy_alignment:
+        warm = min(1.0, step / cfg.surprise_lambda_schedule) if cfg.surprise_lambda_schedule > 0 else 1.0
+        lam_s = cfg.surprise_lambda * warm
+    model._lambda_s = lam_s
+
+    neg_tokens, focus_neg, d_targets, d_masks, is_real = make_negatives(clean_tokens, model.V)
+    tokens_all = torch.cat([clean_tokens, neg_tokens], dim=0)
+    focus_all = torch.cat([torch.zeros_like(focus_neg, dtype=torch.bool), focus_neg], dim=0)
+    H_all, reg_all, logits_all, _tr, energy_all, entropy_all = model.reasoning_loop_batch(tokens_all, cfg.K_inner, focus_all)
+    H_pos, H_neg = H_all[:B], H_all[B:]
+    mask_p, mask_n = reg_all[:B], reg_all[B:]
+    logits_pos, logits_neg = logits_all[:B], logits_all[B:]
+    ce_loss = F.cross_entropy(logits_pos, clean_tokens[:, -1])
+    surprise = model.bank.surprise[0]  # [R]
+    aux_pos = aux_neg = None
+    if cfg.enable_ff_energy_alignment:
+        ms = surprise.mean().expand(B)
+        aux_pos = torch.stack([energy_all[:B], ms, entropy_all[:B]], dim=-1)
+        aux_neg = torch.stack([energy_all[B:], ms, entropy_all[B:]], dim=-1)
+
+    # ---- FF per-region losses on the final states (training.py:120-156), batched over regions
+    ff_loss = torch.tensor(0.0, device=device)
+    gains = None
+    if cfg.enable_forward_forward:
+        gpos = ops.GoodnessFn.apply(H_pos) - lam_s * surprise  # [B,R]
+        gneg = ops.GoodnessFn.apply(H_neg) - lam_s * surprise
+        tau = torch.stack([ff.tau for ff in model.reg_ff])
+        ff_loss = ff_loss + (F.softplus(-(gpos - tau)) + F.softplus(gneg - tau)).mean(0).sum()
+        with torch.no_grad():
+            target = gpos.mean(0)
+            gains = (gpos - gneg).mean(0)
+            if dp is not None:
+                target, gains = dp.mean(target), dp.mean(gains)
+            if cfg.tau_kappa != 0.0:
+                prec = (model.bank.var[0] + EPS_DIV).reciprocal().mean(-1)
+                target = target + cfg.tau_kappa * (prec - cfg.tau_target_prec)
+            new_tau = (1 - 0.01) * tau + 0.01 * target
+            for r, ff in enumerate(model.reg_ff):
+                ff.tau = new_tau[r]
+            model.gate.gain_ema.mul_(0.9).add_((1.0 - 0.9) * gains)
+
+    # ---- RTD on the negative stream's motor state
+    motor = model.io_idxs["motor"]
+    motor_pos, motor_neg = H_pos[:, motor, :], H_neg[:, motor, :]
+    rtd_logits = model.rtdd(motor_neg)
+    rtd_target = (~torch.tensor(is_real, device=device)).long()
+    rtd_loss = F.cross_entropy(rtd_logits, rtd_target)
+    rtd_acc = (rtd_logits.argmax(dim=-1) == rtd_target).float().mean()
+
+    # ---- denoising (mask-predict): first masked position of each negative
+    denoise_loss = torch.tensor(0.0, device=device)
+    hits: List[torch.Tensor] = []
+    for b in range(B):
+        logits_b, aux_b = model.lm_head(motor_neg[b])
+        if bool(d_masks[b].any()):  # host tensors: no device sync
+            idx = int(d_masks[b].nonzero(as_tuple=False)[0].item())
+            target = d_targets[b][idx].unsqueeze(0).to(device)
+            denoise_loss = denoise_loss + F.cross_entropy(logits_b.unsqueeze(0), target) \
+                + aux_b.get("facet_balance", torch.tensor(0.0, device=device)) * λ.facet
+            hits.append((logits_b.argmax(dim=-1) == target[0]).float())
+    denoise_loss = denoise_loss / max(1, B)
+    denoise_acc = torch.stack(hits).mean() if hits else torch.tensor(0.0, device=device)
+
+    # ---- critic regression
+    critic_loss = torch.tensor(0.0, device=device)
+    if not cfg.train_deterministic_inner_loop:
+        realized = (H_pos.pow(2).mean(dim=-1).mean(dim=-1) - H_neg.pow(2).mean(dim=-1).mean(dim=-1)).detach()
+        on = mask_n.to(H_neg.dtype)
+        ws_neg = (H_neg * on.unsqueeze(-1)).sum(1) / on.sum(1, keepdim=True).clamp_min(1.0)
+        _p, g = model.plan(ws_neg, motor_neg)
+        critic_loss = F.mse_loss(model.critic(ws_neg, g), realized)
+
+    # ---- verifier energy FF loss
+    if model.verify is not None and cfg.enable_energy_verifier:
+        y_pos = F.one_hot(clean_tokens[:, -1], num_classes=model.V).float()
+        y_neg = F.softmax(logits_neg.detach(), dim=-1)
+        tau_v = model.verify_state.tau if (cfg.enable_ff_energy_alignment and model.verify_state is not None) else 0.0
+        E_pos = model.verify(motor_pos.detach(), y_pos, aux=aux_pos)
+        E_neg = model.verify(motor_neg.detach(), y_neg, aux=aux_neg)
+        verifier_loss = ff_energy_loss(E_pos, E_neg, tau=tau_v)
+        if cfg.enable_ff_energy_alignment and model.verify_state is not None:
+            Ep, En = E_pos.mean().detach(), E_neg.mean().detach()
+            if dp is not None:
+                Ep, En = dp.mean(Ep), dp.mean(En)
+            model.E_pos_mean = 0.99 * model.E_pos_mean + 0.01 * Ep
+            model.E_neg_mean = 0.99 * model.E_neg_mean + 0.01 * En
+            model.verify_state.update_tau(0.5 * (model.E_pos_mean + model.E_neg_mean))
+    else:
+        E_pos, E_neg = torch.zeros(B, device=device), torch.zeros(B, device=device)
+        verifier_loss = torch.tensor(0.0, device=device)
+
+    total = λ.ff * ff_loss + λ.rtd * rtd_loss + λ.denoise * denoise_loss + λ.critic * critic_loss + λ.verify * verifier_loss
+    total.backward()
+    if dp is not None:
+        dp.sync_grads(model)
+    with torch.no_grad():
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        grad_norm = torch.stack(torch._foreach_norm(grads)).pow(2).sum().sqrt() if grads else torch.tensor(0.0, device=device)
+        # Hebbian nudges on edges whose two ends were active in a positive sample (training.py:147-156,240-243)
+        if gains is not None and model.router.E > 0:
+            router = model.router
+            if router.edge_transform_mode != "per_edge":
+                if bool((gains > 0).any()):
+                    raise AttributeError("Router has no W_edge in this edge_transform_mode (reference training.py:242)")
+            else:
+                t = router._edge_tables(model.reg_coords)
+                Hh = H_pos.detach()
+                mp = mask_p.to(H_pos.dtype)
+                if dp is not None:  # every rank applies the whole global batch's nudges
+                    Hh, mp = dp.gather(Hh), dp.gather(mp)
+                coef = (1e-3 * gains.clamp_min(0.0))[router.dst_idx].unsqueeze(0) * mp[:, router.dst_idx] * mp[:, router.src_idx]
+                ops.hebbian_rank1(router._flat.stacked("W"), t["dst_of_edge"], t["src"], t["widx"], coef, Hh)
+        active_frac = mask_n.float().mean()
+        fired = mask_n.any(dim=0)
+        model.gate.update_homeo(dp.any(fired) if dp is not None else fired)
+    optimizer.step()
+    if cfg.profile and cfg.profile_every_n_steps > 0 and step % cfg.profile_every_n_steps == 0:
+        model.report_profile()
+    vals = torch.stack([t.detach().float().reshape(()) for t in (
+        ff_loss, rtd_loss, denoise_loss, critic_loss, verifier_loss, E_pos.mean(), E_neg.mean(), rtd_acc,
+        denoise_acc, grad_norm, active_frac, ce_loss, total)]).tolist()  # one host sync for all metrics
+    keys = ("ff", "rtd", "denoise", "critic", "verify", "E_pos", "E_neg", "rtd_acc", "denoise_acc", "grad_norm",
+            "active_frac", "ce_last", "total")
+    out = dict(zip(keys, vals))
+    out["E_gap"] = out["E_pos"] - out["E_neg"]
+    out["lambda_s"] = float(lam_s)
+    return out

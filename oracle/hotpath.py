@@ -387,10 +387,14 @@ def router_messages(
     dirs = edge_directions(coords[src], coords[dst]) if mode == "by_direction" else None
     rows = []
     wlist: List[torch.Tensor] = [torch.zeros(()) for _ in range(E)]
+    if not bool(mask_prev[src].any()):  # gate.py:259-260
+        return torch.zeros(R, d), weights
+    # gate.py:293: queries of ALL regions are formed (and so receive a gradient, possibly zero)
+    Q = torch.stack([F.linear(H[r], P["query_W"][r]) for r in range(R)]) if precision else None
     e = 0
     for r in range(R):
         msgs, logws, ids = [], [], []
-        q = F.linear(H[r], P["query_W"][r]) if precision else None
+        q = Q[r] if precision else None
         for s in neighbors[r]:
             eid = e
             e += 1

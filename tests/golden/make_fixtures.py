@@ -28,7 +28,7 @@ from ironcortex.wiring import hex_axial_coords, hex_neighbors  # noqa: E402
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # copy: fixtures must not alias live parameters
 
 
 def save(name, blob):
@@ -264,8 +264,62 @@ def wiring_fixture():
     save("wiring.npz", blob)
 
 
+# ------------------------------------------------------------------ F9/F10/F11: whole model
+MODEL_CASES = {
+    "default": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64),
+    "det": dict(R=7, d=32, V=32, K_inner=4, B_br=2, k_active=4, max_T=64, train_deterministic_inner_loop=True),
+    "allflags": dict(R=10, d=32, V=32, K_inner=3, B_br=2, k_active=5, max_T=64,
+                     enable_adaptive_filter_dynamics=True, enable_precision_routed_messages=True,
+                     enable_radial_tangential_updates=True, enable_afa_attention=True,
+                     enable_ff_energy_alignment=True, surprise_lambda=0.05, tau_kappa=0.01),
+}
+MODEL_B, MODEL_T = 2, 24
+
+
+def model_fixture():
+    import copy
+    import random
+    from ironcortex import CortexConfig, CortexReasoner, LossWeights, train_step
+    for name, kw in MODEL_CASES.items():
+        torch.manual_seed(11); random.seed(11)
+        cfg = CortexConfig(**kw)
+        model = CortexReasoner(hex_neighbors(cfg.R), hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
+        blob = {"sd." + k: npy(v) for k, v in model.state_dict().items()}
+        tokens = (gi.det(31, MODEL_B, MODEL_T, kind="rand") * (cfg.V - 1)).long()
+        focus = gi.det(32, MODEL_B, MODEL_T, kind="rand") < 0.3
+        probe = copy.deepcopy(model)
+        with torch.no_grad():
+            H, m, logits, traces, en, ent = probe.reasoning_loop_batch(tokens, cfg.K_inner, focus)
+        blob["loop.H"] = npy(H); blob["loop.mask"] = npy(m); blob["loop.logits"] = npy(logits)
+        blob["loop.trace0"] = npy(torch.stack(traces[0])); blob["loop.energy"] = npy(en)
+        blob["loop.num"] = npy(torch.stack([r.state_num for r in probe.regions]))
+        blob["loop.pred"] = npy(torch.stack([r.pred for r in probe.regions]))
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        torch.manual_seed(77); random.seed(77)
+        for step in range(2):
+            out = train_step(model, opt, tokens, LossWeights(), torch.device("cpu"))
+            for k, v in out.items():
+                blob[f"step{step}.{k}"] = np.array(v, dtype=np.float64)
+            if step == 0:
+                names = []
+                for n, p in model.named_parameters():
+                    if p.grad is not None:
+                        names.append(n)
+                        blob["gnorm." + n] = np.array(float(p.grad.norm()))
+                        if p.numel() <= 4096 and (n.startswith("regions.0.") or n.startswith("regions.6.") or "W_edge.1->0" in n
+                                                  or n.startswith("norm_in") or n.startswith("router.beta") or "query_lin.1." in n
+                                                  or n.startswith("rtdd") or "raw_P_edge.1->0" in n or "key_lin.1->0" in n):
+                            blob["grad." + n] = npy(p.grad)
+                blob["grad_names"] = np.array(names)
+        blob["final.gain_ema"] = npy(model.gate.gain_ema); blob["final.homeo"] = npy(model.gate.homeo)
+        blob["final.tau"] = npy(torch.stack([f.tau for f in model.reg_ff]))
+        for n, p in model.named_parameters():
+            blob["pnorm." + n] = np.array(float(p.detach().norm()))
+        save(f"model_{name}.npz", blob)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["region", "chain", "kwta", "gate", "router", "wiring"]
+    which = sys.argv[1:] or ["region", "chain", "kwta", "gate", "router", "wiring", "model"]
     for w in which:
         globals()[w + "_fixture"]()

@@ -1,0 +1,58 @@
+"""The reference-shaped oracle model reproduces the REAL reference's whole-step outputs
+(reasoning loop + two train_steps) from the same state_dict, tokens and seeds.  CPU only."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as OM
+from tests.model_cases import MODEL_CASES, load_case, seed_train
+
+KEYS = ("ff", "rtd", "denoise", "critic", "verify", "E_pos", "E_neg", "E_gap", "rtd_acc", "denoise_acc",
+        "grad_norm", "active_frac", "lambda_s", "ce_last", "total")
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_state_dict_keys_and_loop(name):
+    gold, cfg, sd, tokens, focus = load_case(name)
+    model = OM.build(cfg)
+    assert set(model.state_dict().keys()) == set(sd.keys())  # F11: same names
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        H, m, logits, traces, en, ent = copy.deepcopy(model).reasoning_loop_batch(tokens, cfg.K_inner, focus)
+    assert np.array_equal(m.numpy(), gold["loop.mask"])  # identical region selections
+    assert np.array_equal(H.numpy() != 0, gold["loop.H"] != 0)  # identical KWTA winners
+    torch.testing.assert_close(H, torch.as_tensor(gold["loop.H"]), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(logits, torch.as_tensor(gold["loop.logits"]), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(torch.stack(traces[0]), torch.as_tensor(gold["loop.trace0"]), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(en, torch.as_tensor(gold["loop.energy"]), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_two_train_steps(name):
+    gold, cfg, sd, tokens, focus = load_case(name)
+    model = OM.build(cfg)
+    model.load_state_dict(sd)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    seed_train()
+    for step in range(2):
+        out, grads = OM.oracle_train_step(model, opt, tokens, OM.LossWeights(), return_grads=True)
+        for k in KEYS:
+            ref = float(gold[f"step{step}.{k}"])
+            assert out[k] == pytest.approx(ref, rel=2e-4, abs=2e-5), (step, k, out[k], ref)
+        if step == 0:
+            names = set(gold["grad_names"].tolist())
+            assert set(grads.keys()) == names  # same parameters receive a gradient (None elsewhere)
+            for n in names:
+                assert float(grads[n].norm()) == pytest.approx(float(gold["gnorm." + n]), rel=5e-4, abs=1e-6), n
+            for k in gold.files:
+                if k.startswith("grad."):
+                    torch.testing.assert_close(grads[k[5:]], torch.as_tensor(gold[k]), rtol=5e-4, atol=1e-6)
+    torch.testing.assert_close(model.gate.gain_ema, torch.as_tensor(gold["final.gain_ema"]), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(model.gate.homeo, torch.as_tensor(gold["final.homeo"]), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(torch.stack([f.tau for f in model.reg_ff]), torch.as_tensor(gold["final.tau"]), rtol=1e-4, atol=1e-6)
+    for n, p in model.named_parameters():
+        assert float(p.detach().norm()) == pytest.approx(float(gold["pnorm." + n]), rel=1e-5, abs=1e-7), n
