@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — train_step tokens/sec of the IronCortex hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward-forward train_step (corrupt -> reasoning loops over [pos;neg] ->
+losses -> backward -> Hebbian nudges -> AdamW) on one batch of synthetic byte sequences
+resident on the device.  N=1 workload: BASELINE.json configs[1], the ~10M-parameter
+train_tiny_shakespeare_10m.py config (R=10, d=256, all five experimental flags on), B=8
+sequences of T=256 per GPU.  N>1: one process per GPU (torchrun), batch sharded (weak scaling),
+one RCCL exchange per step (ironcortex_amd/parallel.py).  Strict-sequential mode: every rank
+runs the reference's own schedule (samples one after another, region state carried over).
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline      the library kernel with the largest summed duration in the timed region, timed
+                live with HIP events on its launch stream (ic_prof_*), against the HBM peak;
+  cpu_baseline  the CPU oracle model (reference-shaped restatement, kind "port") timed on this
+                box's host cores on a bounded sample of the same workload (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def make_config(name: str):
+    from ironcortex_amd import CortexConfig
+    if name == "10m":  # reference train_tiny_shakespeare_10m.py:32-48
+        return CortexConfig(R=10, d=256, V=256, K_inner=8, B_br=2, k_active=8, max_T=512,
+                            enable_adaptive_filter_dynamics=True, enable_precision_routed_messages=True,
+                            enable_radial_tangential_updates=True, enable_afa_attention=True,
+                            enable_ff_energy_alignment=True, enable_energy_verifier=True,
+                            enable_forward_forward=True, debug_metrics_every_n_steps=2)
+    if name == "default":  # reference train_tiny_shakespeare.py:59-67
+        return CortexConfig(R=36, d=256, V=256, K_inner=8, B_br=2, k_active=8, max_T=512)
+    raise SystemExit(f"unknown --config {name}")
+
+
+WORKLOAD = {"10m": "train_tiny_shakespeare_10m.py config (R=10,d=256,all flags on)",
+            "default": "train_tiny_shakespeare.py default config (R=36,d=256)"}
+
+
+def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
+    """fp32 bytes one launch must move, from per-launch averages:
+    n = active (stream,region) pairs, e = active edges, q = regions with an active in-edge."""
+    n, e, q, R, afd, prec = st["n"], st["e"], st["q"], st["R"], st["afd"], st["prec"]
+    dd = 4.0 * d * d
+    vec = 4.0 * d
+    table = {
+        "region_rkv": n * (3 * dd + (10 + (5 if afd else 0)) * vec),
+        "region_out": n * (dd + 3 * vec),
+        "region_rkv_bwd": n * (3 * dd + (16 + (6 if afd else 0)) * vec),
+        "region_out_bwd": n * (dd + 4 * vec),
+        "router_fwd": e * (dd + vec) + R * vec,
+        "router_edge_fwd": e * (2 * dd + 3 * vec) + q * (dd + 2 * vec),
+        "router_mat_bwd": e * ((2 if prec else 1) * dd + 4 * vec) + (q * (dd + 2 * vec) if prec else 0),
+    }
+    return table.get(kernel, 0.0)
+
+
+def cpu_baseline(cfg_name: str, B: int, T: int, seed: int):
+    """Reference-shaped oracle train_step on the host cores (1 warm-up + 2 timed steps)."""
+    from oracle import model as OM
+    cfg = make_config(cfg_name)
+    torch.manual_seed(seed)
+    random.seed(seed)
+    model = OM.build(cfg)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    tokens = torch.randint(0, 255, (B, T))
+    OM.oracle_train_step(model, opt, tokens, OM.LossWeights())
+    n, t0 = 2, time.perf_counter()
+    for _ in range(n):
+        OM.oracle_train_step(model, opt, tokens, OM.LossWeights())
+    dt = (time.perf_counter() - t0) / n
+    return {"value": B * T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"2 train_steps of the full B={B},T={T} batch after 1 warm-up ({dt:.2f} s/step), "
+                      f"oracle/model.py (reference-shaped per-region Python loop), torch {torch.__version__} CPU",
+            "s_per_step": dt, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="10m")
+    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
+    ap.add_argument("--seq", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import ironcortex_amd as ic
+    from ironcortex_amd import hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        from ironcortex_amd.parallel import DataParallel
+        dist.init_process_group("nccl", device_id=dev)
+        dp = DataParallel()
+
+    cfg = make_config(args.config)
+    torch.manual_seed(1234)
+    random.seed(1234 + rank)
+    R = cfg.R
+    model = ic.CortexReasoner(ic.hex_neighbors(R), ic.hex_axial_coords(R), {"sensor": 0, "motor": R - 1}, cfg).to(dev)
+    if dp is not None:
+        dp.broadcast_module(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    n_params = sum(p.numel() for p in model.parameters())
+    gen = torch.Generator().manual_seed(1234 + rank)
+    B, T = args.batch, args.seq
+    tokens = torch.randint(0, 255, (B, T), generator=gen).to(dev)  # uniform bytes, mask id 255 excluded
+    lw = ic.LossWeights()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dp is not None:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ic.train_step(model, opt, tokens, lw, dev, dp=dp)
+    model.count_units(True)
+    timing = not args.no_kernel_timing
+    if timing:
+        hip.prof_enable(True)
+        hip.prof_read()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        metrics = ic.train_step(model, opt, tokens, lw, dev, dp=dp)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = hip.prof_read() if timing else {}
+    hip.prof_enable(False)
+    units = model.read_units()
+    if dp is not None:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        tok_s = world * B * T * args.steps / elapsed
+        out = {
+            "metric": "train_step tokens/sec (fwd+bwd)", "value": tok_s, "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD[args.config], "per_gpu_batch": B, "global_batch": B * world,
+                       "seq_len": T, "params": n_params, "mode": "strict-sequential (reference schedule)",
+                       "parallelism": f"dp{world}"},
+            "region_steps_per_s": units["region_steps"] / elapsed * world,
+            "inner_steps_per_s": units["inner_steps"] / elapsed * world,
+            "loss_total": metrics["total"],
+        }
+        roof = None
+        if prof:
+            lib_ms = sum(ms for _, ms in prof.values())
+            name = max((k for k in prof if algorithmic_bytes(k, cfg.d, dict(n=1, e=1, q=1, R=R, afd=0, prec=0)) > 0),
+                       key=lambda k: prof[k][1])
+            launches, ms = prof[name]
+            inner = max(1, units["inner_steps"])
+            st = dict(n=units["region_steps"] / inner, e=units["active_edges"] / inner, q=units["dst_regions"] / inner,
+                      R=R, afd=cfg.enable_adaptive_filter_dynamics, prec=cfg.enable_precision_routed_messages)
+            ab = algorithmic_bytes(name, cfg.d, st)
+            avg_s = ms / launches * 1e-3
+            achieved = ab / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": "k_" + name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                    "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ab,
+                    "units_per_launch": {"active_regions": st["n"], "active_edges": st["e"]},
+                    "library_kernel_ms_per_step": lib_ms / args.steps,
+                    "note": "working set fits the 256 MB Infinity Cache; launches are latency-bound at this size "
+                            "(see profiles/ for the R=64..512 kernel sweep)"}
+            out["kernels_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        out["roofline"] = roof
+        cb = None
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.config, B, T, 1234)
+        out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if dp is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

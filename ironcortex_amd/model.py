@@ -84,12 +84,24 @@ class CortexReasoner(nn.Module):
         self._profile_mem = {"attention": 0, "routing": 0, "region": 0}
         self._sensor_cache = None
         self.counters = {"inner_steps": 0}
+        self._units = None  # device counters for bench.py (off by default)
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, recurse=True):
         super()._apply(fn, recurse)
         self.bank.to_device()
         return self
+
+    def count_units(self, on: bool) -> None:
+        """Count region steps / active edges on the device (no sync) for throughput reports."""
+        dev = self.reg_coords.device
+        self._units = torch.zeros(3, device=dev) if on else None
+        self.counters["inner_steps"] = 0
+
+    def read_units(self) -> Dict[str, float]:
+        u = self._units.tolist() if self._units is not None else [0.0, 0.0, 0.0]
+        return {"inner_steps": self.counters["inner_steps"], "region_steps": u[0], "active_edges": u[1],
+                "dst_regions": u[2]}
 
     def detach_state(self) -> None:
         if hasattr(self, "work"):
@@ -187,6 +199,10 @@ class CortexReasoner(nn.Module):
             self._profile_times["region"] += t2 - t1
             self._profile_times["total"] += t2 - t_total
         self.counters["inner_steps"] += 1
+        if self._units is not None and self.router.E > 0:
+            ea = reg_mask_prev.to(torch.float32)[self.router.src_idx]
+            into = torch.zeros(self.R, device=dev).index_add_(0, self.router.dst_idx, ea)
+            self._units += torch.stack([mask.sum().float(), ea.sum(), (into > 0).sum().float()])
         # 4) heads on motor & workspace
         reg_mask = mask[0].bool()
         active = reg_mask.nonzero(as_tuple=False).squeeze(-1)
