@@ -213,6 +213,23 @@ class Router(nn.Module):
         b = (c * self.beta_cos + s * self.beta_sin).sum(-1) * self.fb_scale
         return 1.0 + self.fb_alpha * b
 
+    def begin_loop(self) -> None:
+        """Inside one reasoning loop the bias parameters are fixed: compute 1 + alpha*b once."""
+        self._bias_cache = "armed"
+
+    def end_loop(self) -> None:
+        self._bias_cache = None
+
+    def _cached_bias(self, reg_coords: torch.Tensor) -> torch.Tensor:
+        c = getattr(self, "_bias_cache", None)
+        if c is None:
+            return self._edge_bias(reg_coords)
+        key = (torch.is_grad_enabled(), self.fb_alpha, self.beta_cos._version)
+        if c == "armed" or c[0] != key:
+            c = (key, self._edge_bias(reg_coords))
+            self._bias_cache = c
+        return c[1]
+
     def _params(self) -> Dict[str, torch.Tensor]:
         f = self._flat
         return {"W": f.stacked("W"), "key_W": f.stacked("key_W"), "raw_P": f.stacked("raw_P"),
@@ -266,7 +283,7 @@ class Router(nn.Module):
         if self._flat.flat.device != dev:
             raise RuntimeError("Router parameters and input are on different devices")
         tables = self._edge_tables(reg_coords)
-        ebias = self._edge_bias(reg_coords)
+        ebias = self._cached_bias(reg_coords)
         spec = ops.RouterSpec(self.R, self.d, self.E, self.nW, self.enable_precision_routed_messages)
         box = dict(spec=spec, tables=tables, P=self._params(), mask_prev=mask_prev.contiguous(),
                    tape=self._get_tape(S, dev), coord=self._coord, grad_sink=self._grad_sink)

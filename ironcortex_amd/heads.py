@@ -89,6 +89,18 @@ class TokenHead_MFS(nn.Module):
         self.gate = nn.Linear(d, Kf)
         self.facets = nn.ModuleList([nn.Linear(d, V) for _ in range(Kf)])
 
+    def stacked(self):
+        """([Kf + Kf*V, d], [Kf + Kf*V]) gate and facet weights as one matrix (one GEMV per call)."""
+        W = torch.cat([self.gate.weight] + [f.weight for f in self.facets], dim=0)
+        b = torch.cat([self.gate.bias] + [f.bias for f in self.facets], dim=0)
+        return W, b
+
+    def forward_stacked(self, x: torch.Tensor, Wb) -> torch.Tensor:
+        """Same result as forward(x)[0] from the stacked weights."""
+        z = F.linear(x, Wb[0], Wb[1])
+        g = F.softmax(z[: self.Kf], dim=-1)
+        return (g.unsqueeze(-1) * z[self.Kf:].view(self.Kf, self.V)).sum(dim=0)
+
     def forward(self, x: torch.Tensor, targets: Optional[torch.Tensor] = None):
         g = F.softmax(self.gate(x), dim=-1)
         per_facet = torch.stack([f(x) for f in self.facets], dim=0)

@@ -85,6 +85,9 @@ class CortexReasoner(nn.Module):
         self._sensor_cache = None
         self.counters = {"inner_steps": 0}
         self._units = None  # device counters for bench.py (off by default)
+        self._loop_cache = None
+        self._in_loop = False
+        self._heads_used = None
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, recurse=True):
@@ -203,25 +206,55 @@ class CortexReasoner(nn.Module):
             ea = reg_mask_prev.to(torch.float32)[self.router.src_idx]
             into = torch.zeros(self.R, device=dev).index_add_(0, self.router.dst_idx, ea)
             self._units += torch.stack([mask.sum().float(), ea.sum(), (into > 0).sum().float()])
-        # 4) heads on motor & workspace
+        # 4) heads on motor & workspace -- no host sync: the active set stays on the device
         reg_mask = mask[0].bool()
-        active = reg_mask.nonzero(as_tuple=False).squeeze(-1)
-        active_list = active.tolist()  # the one host sync of the step
+        on = reg_mask.to(H_cur.dtype)
         motor = self.io_idxs["motor"]
         motor_state = H_cur[motor]
-        delta = torch.zeros_like(self.work.slots)
-        n_write = min(len(active_list), delta.shape[0])
-        if n_write > 0:
-            delta[:n_write] = H_cur[active[:n_write]]
-            self.work.write(delta)
-            ws_state = self.work.slots.mean(dim=0)
-        else:
-            ws_state = torch.zeros(self.d, device=dev)
-        motor_logits, _ = self.lm_head(motor_state)
-        parts = [motor_logits] + [self.region_heads[r](H_cur[r]) for r in active_list if r != motor]
-        logits = torch.stack(parts, dim=0).mean(dim=0)
+        # first N_slots active regions (index order) write the workspace (model.py:300-306)
+        n_slots = self.work.slots.shape[0]
+        rank = torch.cumsum(reg_mask.to(torch.int64), 0) - 1
+        slot = torch.where(reg_mask & (rank < n_slots), rank, torch.full_like(rank, n_slots))
+        delta = torch.zeros(n_slots + 1, self.d, device=dev).index_add_(0, slot, H_cur)[:n_slots]
+        self.work.write(delta)  # io regions are forced on, so at least one region always writes
+        ws_state = self.work.slots.mean(dim=0)
+        # token logits: mean of the motor head and the heads of the other active regions (model.py:311-318)
+        cache = self._head_cache()
+        motor_logits = self.lm_head.forward_stacked(motor_state, cache["lm"])
+        Wst, bst = cache["region_heads"]
+        per_region = torch.baddbmm(bst.unsqueeze(-1), Wst, H_cur.unsqueeze(-1)).squeeze(-1)  # [R,V]
+        w = on.clone()
+        w[motor] = 0.0
+        logits = (motor_logits + (w.unsqueeze(-1) * per_region).sum(0)) / (1.0 + w.sum())
+        if self._heads_used is None or self._heads_used.device != dev:
+            self._heads_used = torch.zeros(self.R, dtype=torch.bool, device=dev)
+        self._heads_used |= w.bool()
         rtd_logits = self.rtdd(motor_state)
         return H_cur, reg_mask, logits, rtd_logits, ws_state, motor_state
+
+    def _head_cache(self):
+        """Stacked views of the token heads, rebuilt once per reasoning loop (the parameters do
+        not change inside one); gradients flow back through the stack to the per-head Parameters."""
+        c = self._loop_cache
+        key = (torch.is_grad_enabled(), self.region_heads[0].weight._version, self.region_heads[0].weight.data_ptr())
+        if c is None or c.get("key") != key or not self._in_loop:
+            c = {"key": key, "lm": self.lm_head.stacked(),
+                 "region_heads": (torch.stack([h.weight for h in self.region_heads]),
+                                  torch.stack([h.bias for h in self.region_heads]))}
+            self._loop_cache = c
+        return c
+
+    def finalize_grads(self) -> None:
+        """After backward: region heads that never contributed keep grad None, as in the
+        reference where only the heads of active regions enter the graph (one host sync)."""
+        if self._heads_used is None:
+            return
+        used = self._heads_used.tolist()
+        for r, h in enumerate(self.region_heads):
+            if not used[r]:
+                h.weight.grad = None
+                h.bias.grad = None
+        self._heads_used.zero_()
 
     @torch.no_grad()
     def zeros_state(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -238,8 +271,19 @@ class CortexReasoner(nn.Module):
     def reasoning_loop(self, tokens: torch.Tensor, K_inner: int, focus_map: torch.Tensor,
                        reg_mask_prev: torch.Tensor, H_prev: torch.Tensor):
         """plan -> critic -> gate; branch; verify; halt (model.py:329-460)."""
-        dev = H_prev.device
         self._sensor_cache = None
+        self._loop_cache = None
+        self._in_loop = True
+        self.router.begin_loop()
+        try:
+            return self._reasoning_loop(tokens, K_inner, focus_map, reg_mask_prev, H_prev)
+        finally:
+            self._in_loop = False
+            self._loop_cache = None
+            self.router.end_loop()
+
+    def _reasoning_loop(self, tokens, K_inner, focus_map, reg_mask_prev, H_prev):
+        dev = H_prev.device
         last_logits = torch.zeros(self.V, device=dev)
         traces: List[torch.Tensor] = []
         if self.cfg.train_deterministic_inner_loop:
@@ -261,8 +305,9 @@ class CortexReasoner(nn.Module):
             n_on = on.sum()
             # mean of the previously active rows (zeros when none): no host sync needed
             ws_prev = (H_prev * on.unsqueeze(-1)).sum(0) / n_on.clamp_min(1.0)
-            _p, g = self.plan(ws_prev, H_prev[motor])
-            v_hat = float(self.critic(ws_prev, g).item())
+            with torch.no_grad():  # v_hat only steers the gate (model.py:381-386)
+                _p, g = self.plan(ws_prev, H_prev[motor])
+                v_hat = float(self.critic(ws_prev, g).item())
             self.gate.value_bias = v_hat
             burst = schedule_burst(u_mean, v_hat, self.R)
             for b in range(self.cfg.B_br):
@@ -270,9 +315,10 @@ class CortexReasoner(nn.Module):
                 H_b, m_b = branches[b][2].clone(), branches[b][1].clone()
                 H_cur, reg_mask, logits, _rtd, _ws, motor_state = self.forward_inner_step(
                     tokens, k, focus_map, H_b, m_b, u_mean, burst)
-                ver_energy = self.verify(motor_state, F.softmax(logits.detach(), dim=-1), aux=self._verify_aux(dev))
-                delta_g = goodness(H_cur) - goodness(H_b)
-                scores[b] = 0.6 * delta_g + 0.2 * (-ver_energy) + 0.2 * context_logprob(logits)
+                with torch.no_grad():  # branch scores only rank the branches (model.py:425-438)
+                    ver_energy = self.verify(motor_state, F.softmax(logits, dim=-1), aux=self._verify_aux(dev))
+                    delta_g = goodness(H_cur) - goodness(H_b)
+                    scores[b] = 0.6 * delta_g + 0.2 * (-ver_energy) + 0.2 * context_logprob(logits)
                 branches[b] = (self.work.slots.clone(), reg_mask.clone(), H_cur.clone())
                 last_logits = logits
             top = torch.topk(torch.stack(scores), k=min(self.cfg.B_br, 2)).indices.tolist()

@@ -150,6 +150,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
 
     total = λ.ff * ff_loss + λ.rtd * rtd_loss + λ.denoise * denoise_loss + λ.critic * critic_loss + λ.verify * verifier_loss
     total.backward()
+    model.finalize_grads()
     if dp is not None:
         dp.sync_grads(model)
     with torch.no_grad():

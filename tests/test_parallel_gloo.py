@@ -1,0 +1,74 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel exchange used by train_step(dp=...)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ironcortex_amd.flat import ArenaParameter, FlatParams
+        from ironcortex_amd.parallel import DataParallel
+        dp = DataParallel()
+        torch.manual_seed(7)  # identical replicas
+        lin = torch.nn.Linear(4, 3)
+        a, b, c = (ArenaParameter(torch.randn(2, 2)) for _ in range(3))
+        flat = FlatParams({"W": [a, b, c]})
+        mod = torch.nn.Module()
+        mod.lin, mod.a, mod.b, mod.c = lin, a, b, c
+        # rank-dependent gradients; b has a gradient only on rank 1, c on no rank
+        lin.weight.grad = torch.full((3, 4), float(rank + 1))
+        lin.bias.grad = None if rank == 0 else torch.ones(3)
+        flat.begin_pass()
+        flat.stacked_grad("W")[0].fill_(rank + 1.0)
+        flat.publish("W", [True, rank == 1, False])
+        if rank == 1:
+            flat.stacked_grad("W")[1].fill_(4.0)
+        dp.sync_grads(mod)
+        out = {
+            "w": lin.weight.grad.clone(), "bias": lin.bias.grad.clone(), "a": a.grad.clone(), "b": b.grad.clone(),
+            "c_none": c.grad is None, "mean": dp.mean(torch.tensor([float(rank)])),
+            "any": dp.any(torch.tensor([rank == 1, False])), "gather": dp.gather(torch.full((2, 3), float(rank))),
+        }
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_exchange_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        o = res[r]
+        assert torch.allclose(o["w"], torch.full((3, 4), 1.5))      # mean of 1 and 2
+        assert torch.allclose(o["bias"], torch.full((3,), 0.5))     # None on rank 0 counts as zero
+        assert torch.allclose(o["a"], torch.full((2, 2), 1.5))
+        assert torch.allclose(o["b"], torch.full((2, 2), 2.0))      # (0 + 4) / 2, rank 0 had None
+        assert o["c_none"]                                          # None everywhere stays None
+        assert torch.allclose(o["mean"], torch.tensor([0.5]))
+        assert o["any"].tolist() == [True, False]
+        assert torch.equal(o["gather"], torch.cat([torch.zeros(2, 3), torch.ones(2, 3)]))
+    # replicas end identical
+    for k in ("w", "bias", "a", "b"):
+        assert torch.equal(res[0][k], res[1][k])
