@@ -6,14 +6,16 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .heads import VecLinear
+
 
 class EnergyVerifierHead(nn.Module):
     def __init__(self, ctx_dim: int, y_dim: int, hidden: int, *, aux_dim: int = 0):
         super().__init__()
         self.aux_dim = aux_dim
         n_in = ctx_dim + y_dim + aux_dim
-        self.net = nn.Sequential(nn.LayerNorm(n_in), nn.Linear(n_in, hidden), nn.SiLU(),
-                                 nn.Linear(hidden, hidden), nn.SiLU(), nn.Linear(hidden, 1))
+        self.net = nn.Sequential(nn.LayerNorm(n_in), VecLinear(n_in, hidden), nn.SiLU(),
+                                 VecLinear(hidden, hidden), nn.SiLU(), VecLinear(hidden, 1))
 
     def forward(self, ctx: torch.Tensor, y_hat: torch.Tensor, aux: torch.Tensor | None = None) -> torch.Tensor:
         parts = [ctx, y_hat]

@@ -134,7 +134,8 @@ def set_field(obj, name: str, value) -> None:
 def stream_handle():
     import torch
 
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of torch's current stream (0.1 us; torch.cuda.current_stream() costs ~3 us)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def prof_enable(on: bool) -> None:
