@@ -11,7 +11,6 @@
 
 namespace {
 
-constexpr int kRowsPerBlock = 8;  // 4 waves x one channel pair
 
 // ---------------------------------------------------------------- prologue (wave per row)
 template <int DCH>
@@ -78,105 +77,124 @@ __device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int 
 }
 
 // ---------------------------------------------------------------- r,k,v GEMVs + state update
-template <int DCH>
+// PP = channel pairs per wave: a workgroup owns 8*PP rows of W_r, W_k, W_v (24*PP KiB at d=256),
+// all loaded up front so every wave keeps 6*PP independent 1 KiB row requests in flight.
+template <int DCH, int PP>
 __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
   const int r = blockIdx.y;
   if (!region_has_work(a.mask, a.S, a.R, r)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
-  const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;  // even: a rotation pair
+  const int row0 = blockIdx.x * (8 * PP) + wave * (2 * PP);  // even: rotation pairs stay in one wave
   if (row0 >= d) return;
   const size_t dd = (size_t)d * d;
   const float* Wr = a.W + (size_t)r * 4 * dd;
   const float* Wk = Wr + dd;
   const float* Wv = Wk + dd;
-  RowFrag<DCH> wr[2], wk[2], wv[2];
+  RowFrag<DCH> wr[2 * PP], wk[2 * PP], wv[2 * PP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    load_row(wr[i], Wr + (size_t)(row0 + i) * d, d, lane);
-    load_row(wk[i], Wk + (size_t)(row0 + i) * d, d, lane);
-    load_row(wv[i], Wv + (size_t)(row0 + i) * d, d, lane);
+  for (int i = 0; i < 2 * PP; ++i) {
+    if (row0 + i < d) {  // wave-uniform (d is even)
+      load_row(wr[i], Wr + (size_t)(row0 + i) * d, d, lane);
+      load_row(wk[i], Wk + (size_t)(row0 + i) * d, d, lane);
+      load_row(wv[i], Wv + (size_t)(row0 + i) * d, d, lane);
+    } else {
+      zero_frag(wr[i]); zero_frag(wk[i]); zero_frag(wv[i]);
+    }
   }
   const bool afd = a.flags & IC_F_AFD;
-  const int ch = row0 + (lane & 1);  // lanes 0/1 finish one channel each
-  // per-channel constants
-  const float rate = -ic_softplus(a.raw_decay[(size_t)r * d + ch]);  // region.py:94-95
-  float pn = 0.f, on = 0.f;
-  if (afd) {
-    const bool vec = a.flags & IC_F_NOISE_VEC;
-    pn = ic_noise(vec ? a.pn_param[(size_t)r * d + ch] : a.pn_param[r]);
-    on = ic_noise(vec ? a.on_param[(size_t)r * d + ch] : a.on_param[r]);
-  }
-  float rc = 1.f, rs = 0.f;
-  const bool rot = ch < 2 * a.m_time;
-  if (rot) {
-    float th = a.step_pos * a.W_time[ch >> 1];  // region.py:186
-    rc = cosf(th);
-    rs = sinf(th);
+  // per-channel constants; lanes 0/1 finish one channel of each pair
+  float rate[PP], pn[PP], on[PP], rc[PP], rs[PP];
+  bool rot[PP], ok[PP];
+#pragma unroll
+  for (int p = 0; p < PP; ++p) {
+    const int chr = row0 + 2 * p + (lane & 1);
+    ok[p] = chr < d;
+    const int ch = ok[p] ? chr : 0;
+    rate[p] = -ic_softplus(a.raw_decay[(size_t)r * d + ch]);  // region.py:94-95
+    pn[p] = on[p] = 0.f;
+    if (afd) {
+      const bool vec = a.flags & IC_F_NOISE_VEC;
+      pn[p] = ic_noise(vec ? a.pn_param[(size_t)r * d + ch] : a.pn_param[r]);
+      on[p] = ic_noise(vec ? a.on_param[(size_t)r * d + ch] : a.on_param[r]);
+    }
+    rc[p] = 1.f;
+    rs[p] = 0.f;
+    rot[p] = ch < 2 * a.m_time;
+    if (rot[p]) {
+      const float th = a.step_pos * a.W_time[ch >> 1];  // region.py:186
+      rc[p] = cosf(th);
+      rs[p] = sinf(th);
+    }
   }
   for (int s = 0; s < a.S; ++s) {
     const int row = s * a.R + r;
     if (!a.mask[row]) continue;
     RowFrag<DCH> xv;
     load_row(xv, a.x + (size_t)row * d, d, lane);
-    float pr0 = wave_sum(dot_frag(wr[0], xv)), pr1 = wave_sum(dot_frag(wr[1], xv));
-    float pk0 = wave_sum(dot_frag(wk[0], xv)), pk1 = wave_sum(dot_frag(wk[1], xv));
-    float pv0 = wave_sum(dot_frag(wv[0], xv)), pv1 = wave_sum(dot_frag(wv[1], xv));
-    if (lane < 2) {
-      const size_t idx = (size_t)row * d + ch;
-      const float rr = ic_sigmoid(lane ? pr1 : pr0);
-      const float kk = lane ? pk1 : pk0;
-      float vv = lane ? pv1 : pv0;
-      if (rot) vv = lane ? (pv0 * rs + pv1 * rc) : (pv0 * rc - pv1 * rs);  // iron_rope.py:63-64
-      const float steps = (float)(a.dt[row] + 1);
-      const float lam = fmaxf(expf(rate * steps), IC_EPS_DIV);  // region.py:97-98
-      const float numd = a.num[idx] * lam, dend = a.den[idx] * lam;  // region.py:131-133
-      const float w = expf(fminf(kk, IC_MAX_EXP));  // region.py:190
-      float yv, num_n, den_n;
-      if (afd) {  // region.py:192-212
-        const float vard = a.var[idx] * (lam * lam) + pn * steps;  // region.py:135
-        const float prd = numd / (dend + IC_EPS_DIV);
-        const float resid = w * vv - prd;
-        const float obs = expf(fminf(-kk, IC_MAX_EXP)) * on + IC_EPS_DIV;
-        float gain = vard / (vard + obs);
-        gain = fminf(fmaxf(gain, IC_EPS_DIV), 1.0f);  // fp32(1 - 1e-8) == 1
-        const float st = prd + gain * resid;
-        den_n = dend + w;
-        num_n = st * den_n;
-        a.var_o[idx] = (1.0f - gain) * vard;
-        a.sterm[idx] = (resid * resid) * (1.0f / (vard + obs));
-        yv = rr * st;
-      } else {  // region.py:214-216
-        num_n = numd + w * vv;
-        den_n = dend + w;
-        yv = rr * (num_n / (den_n + IC_EPS_DIV));
+    const float steps = (float)(a.dt[row] + 1);
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const float pr0 = wave_sum(dot_frag(wr[2 * p], xv)), pr1 = wave_sum(dot_frag(wr[2 * p + 1], xv));
+      const float pk0 = wave_sum(dot_frag(wk[2 * p], xv)), pk1 = wave_sum(dot_frag(wk[2 * p + 1], xv));
+      const float pv0 = wave_sum(dot_frag(wv[2 * p], xv)), pv1 = wave_sum(dot_frag(wv[2 * p + 1], xv));
+      if (lane < 2 && ok[p]) {
+        const size_t idx = (size_t)row * d + row0 + 2 * p + lane;
+        const float rr = ic_sigmoid(lane ? pr1 : pr0);
+        const float kk = lane ? pk1 : pk0;
+        float vv = lane ? pv1 : pv0;
+        if (rot[p]) vv = lane ? (pv0 * rs[p] + pv1 * rc[p]) : (pv0 * rc[p] - pv1 * rs[p]);  // iron_rope.py:63-64
+        const float lam = fmaxf(expf(rate[p] * steps), IC_EPS_DIV);  // region.py:97-98
+        const float numd = a.num[idx] * lam, dend = a.den[idx] * lam;  // region.py:131-133
+        const float w = expf(fminf(kk, IC_MAX_EXP));  // region.py:190
+        float yv, num_n, den_n;
+        if (afd) {  // region.py:192-212
+          const float vard = a.var[idx] * (lam * lam) + pn[p] * steps;  // region.py:135
+          const float prd = numd / (dend + IC_EPS_DIV);
+          const float resid = w * vv - prd;
+          const float obs = expf(fminf(-kk, IC_MAX_EXP)) * on[p] + IC_EPS_DIV;
+          float gain = vard / (vard + obs);
+          gain = fminf(fmaxf(gain, IC_EPS_DIV), 1.0f);  // fp32(1 - 1e-8) == 1
+          const float st = prd + gain * resid;
+          den_n = dend + w;
+          num_n = st * den_n;
+          a.var_o[idx] = (1.0f - gain) * vard;
+          a.sterm[idx] = (resid * resid) * (1.0f / (vard + obs));
+          yv = rr * st;
+        } else {  // region.py:214-216
+          num_n = numd + w * vv;
+          den_n = dend + w;
+          yv = rr * (num_n / (den_n + IC_EPS_DIV));
+        }
+        a.num_o[idx] = num_n;
+        a.den_o[idx] = den_n;
+        a.y[idx] = yv;
+        a.r_s[idx] = rr;
+        a.k_s[idx] = kk;
+        a.v_s[idx] = vv;
       }
-      a.num_o[idx] = num_n;
-      a.den_o[idx] = den_n;
-      a.y[idx] = yv;
-      a.r_s[idx] = rr;
-      a.k_s[idx] = kk;
-      a.v_s[idx] = vv;
     }
   }
 }
 
 // ---------------------------------------------------------------- output projection (+ radial/tangential)
-template <int DCH>
+template <int DCH, int PP>
 __global__ __launch_bounds__(256) void k_region_out(ic_region_args a) {
   const int r = blockIdx.y;
   if (!region_has_work(a.mask, a.S, a.R, r)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
-  const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
+  const int row0 = blockIdx.x * (8 * PP) + wave * (2 * PP);
   if (row0 >= d) return;
   const size_t dd = (size_t)d * d;
   const float* Wo = a.W + ((size_t)r * 4 + 3) * dd;
-  RowFrag<DCH> wo[2];
-  load_row(wo[0], Wo + (size_t)row0 * d, d, lane);
-  load_row(wo[1], Wo + (size_t)(row0 + 1) * d, d, lane);
+  RowFrag<DCH> wo[2 * PP];
+#pragma unroll
+  for (int i = 0; i < 2 * PP; ++i) {
+    if (row0 + i < d) load_row(wo[i], Wo + (size_t)(row0 + i) * d, d, lane);
+    else zero_frag(wo[i]);
+  }
   const bool rt = a.flags & IC_F_RT;
-  const int ch = row0 + (lane & 1);
   for (int s = 0; s < a.S; ++s) {
     const int row = s * a.R + r;
     if (!a.mask[row]) continue;
@@ -206,11 +224,15 @@ __global__ __launch_bounds__(256) void k_region_out(ic_region_args a) {
         }
       }
     }
-    float h0 = wave_sum(dot_frag(wo[0], yv)), h1 = wave_sum(dot_frag(wo[1], yv));
-    if (lane < 2) {
-      const size_t idx = (size_t)row * d + ch;
-      const float hd = lane ? h1 : h0;
-      a.hpre[idx] = a.x[idx] + (rt ? scale * hd : hd);
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const float h0 = wave_sum(dot_frag(wo[2 * p], yv)), h1 = wave_sum(dot_frag(wo[2 * p + 1], yv));
+      const int ch = row0 + 2 * p + lane;
+      if (lane < 2 && ch < d) {
+        const size_t idx = (size_t)row * d + ch;
+        const float hd = lane ? h1 : h0;
+        a.hpre[idx] = a.x[idx] + (rt ? scale * hd : hd);
+      }
     }
   }
 }
@@ -383,14 +405,26 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
   const int rows = a->S * a->R;
   const dim3 blk(256);
   const dim3 grow(ic_ceil_div(rows, 4));
-  const dim3 gmat(ic_ceil_div(a->d, kRowsPerBlock), a->R);
+  // rows per workgroup in the GEMV kernels: 8 (many small workgroups: best when few regions are
+  // active and the launch is latency-bound), 16 or 32 (deeper per-wave load queues: best when the
+  // launch streams hundreds of MiB).  rows_fwd = 0 lets the library choose from the problem size.
+  int rpb = a->rows_fwd;
+  if (rpb == 0) rpb = 8;
+  IC_REQUIRE(rpb == 8 || rpb == 16 || rpb == 32, "ic_region_phase_fwd: rows_fwd=%d (need 0, 8, 16 or 32)", rpb);
+  if (a->d > 256 && rpb > 16) rpb = 16;  // register budget at DCH >= 2
+  const dim3 gmat(ic_ceil_div(a->d, rpb), a->R);
   const float oma = (float)(1.0 - a->pred_alpha);
-  IC_DISPATCH_DCH(a->d, {
-    IC_TIMED(IC_KID_region_pro, st, hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a));
-    IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL(k_region_rkv<DCH>, gmat, blk, 0, st, *a));
-    IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL(k_region_out<DCH>, gmat, blk, 0, st, *a));
-    IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma));
-  });
+#define IC_FWD_LAUNCH(PP)                                                                                   \
+  IC_DISPATCH_DCH(a->d, {                                                                                   \
+    IC_TIMED(IC_KID_region_pro, st, hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a));           \
+    IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP>), gmat, blk, 0, st, *a));     \
+    IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL((k_region_out<DCH, PP>), gmat, blk, 0, st, *a));     \
+    IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma));      \
+  })
+  if (rpb == 8) IC_FWD_LAUNCH(1);
+  else if (rpb == 16) IC_FWD_LAUNCH(2);
+  else IC_FWD_LAUNCH(4);
+#undef IC_FWD_LAUNCH
   IC_LAUNCH_CHECK("ic_region_phase_fwd");
   return IC_OK;
 }

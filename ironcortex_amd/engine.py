@@ -1,0 +1,557 @@
+"""LoopEngine: the reasoning loop of one sequence as a straight run of C-ABI calls.
+
+The general path (CortexReasoner.forward_inner_step) wraps every gate/router/region call in its
+own torch.autograd.Function and allocates every output with torch.empty; at one sequence per
+loop that host work is ten times the GPU work.  The engine runs the same kernels on the same
+inputs, but
+
+  * all per-step tensors (outputs, saved activations, masks) live in a step arena: one pointer
+    addition per field instead of an allocation, and a step's saved activations stay where the
+    forward kernels wrote them until the backward reads them;
+  * the C structs are built once per loop and only the moving pointers are patched per step;
+  * autograd sees ONE node per loop (LoopFn).  Its backward walks the recorded steps in reverse
+    with two C calls per step (ic_region_phase_bwd, ic_router_bwd), carrying the state
+    gradients (num, den, var, pred, radius) from step to step and the H gradients from a
+    step to the step that produced its input, exactly the chain torch autograd would follow;
+  * the heads that only steer the loop (token logits, workspace, planner/critic, verifier) run
+    without autograd.
+
+It is used when the caller needs gradients only through the loop's final region states (the
+forward-forward train_step: reference training.py:120-231 never back-propagates through the
+inner-step logits) or no gradients at all (generation, evaluation).  Anything else takes the
+general path.  Results are identical up to fp32 summation order of the small parameter
+gradients (per-step rows are summed per loop instead of accumulated step by step).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .hip import check, lib, new, ops, stream_handle
+from .utils import context_logprob, goodness, schedule_burst, should_halt
+
+_F32, _I32, _U8 = torch.float32, torch.int32, torch.uint8
+
+
+class _Chunk:
+    """cap steps of every field, field-major: fields[name] is [cap, *shape]."""
+
+    def __init__(self, shapes: Dict[str, Tuple[tuple, torch.dtype]], cap: int, device):
+        self.cap = cap
+        self.fields = {k: torch.zeros((cap,) + tuple(s), dtype=dt, device=device) for k, (s, dt) in shapes.items()}
+        self.ptr = {k: t.data_ptr() for k, t in self.fields.items()}
+        self.stride = {k: t.stride(0) * t.element_size() for k, t in self.fields.items()}
+
+
+class StepArena:
+    """Chunks of step slots.  reserve(n) returns n contiguous slots; nothing moves on growth, so
+    device pointers handed out earlier stay valid until reset()."""
+
+    def __init__(self, shapes, chunk_steps: int = 128):
+        self.shapes, self.chunk_steps = shapes, chunk_steps
+        self.chunks: List[_Chunk] = []
+        self.cur, self.pos = 0, 0
+
+    def reserve(self, n: int, device) -> Tuple[_Chunk, int]:
+        while True:
+            if self.cur >= len(self.chunks):
+                self.chunks.append(_Chunk(self.shapes, max(self.chunk_steps, n), device))
+            c = self.chunks[self.cur]
+            if c.cap - self.pos >= n:
+                start = self.pos
+                self.pos += n
+                return c, start
+            self.cur, self.pos = self.cur + 1, 0
+
+    def reset(self) -> None:
+        self.cur, self.pos = 0, 0
+
+
+class _Sample:
+    """Record of one loop: what the backward needs to replay the steps in reverse."""
+
+    __slots__ = ("chunk", "i0", "n", "parent", "best", "step_pos", "init", "H0", "mask0", "sensor", "ebias",
+                 "norm_in_w", "flags", "kwta_k", "kwta_temp", "keep")
+
+
+class LoopEngine:
+    def __init__(self, model):
+        self.model = model
+        self.enabled = True
+        self._arena: Optional[StepArena] = None
+        self._arena_key = None
+        self._ws = None
+        self._samples_alive = 0
+
+    # ------------------------------------------------------------------ applicability
+    def usable(self, H_prev: torch.Tensor, logits_need_grad: bool) -> bool:
+        m = self.model
+        if not self.enabled or not H_prev.is_cuda or H_prev.requires_grad:
+            return False
+        if torch.is_grad_enabled() and logits_need_grad:
+            return False
+        if m.cfg.profile or m.cfg.ff_dropout:
+            return False
+        b = m.bank
+        if b.S != 1 or b.num.device != H_prev.device:
+            return True  # the first phase() call builds the state; done in run()
+        return not any(getattr(b, k).requires_grad for k in ("num", "den", "var", "pred", "radius", "radius_var"))
+
+    def reset(self) -> None:
+        """Start of a new forward/backward pass: every step slot may be reused."""
+        if self._arena is not None:
+            self._arena.reset()
+
+    # ------------------------------------------------------------------ storage
+    def _shapes(self):
+        m = self.model
+        b, rt = m.bank, m.router
+        R, d, E = m.R, m.d, max(rt.E, 1)
+        rd = ((R, d), _F32)
+        sh = {"H": rd, "num_o": rd, "den_o": rd, "dt_o": ((R,), _I32), "M": rd, "scores": ((R,), _F32),
+              "mask": ((R,), _U8), "inv_s": ((R, 2), _F32)}
+        for k in ("x", "u1", "r_s", "k_s", "v_s", "y", "hpre", "gate"):
+            sh[k] = rd
+        if b.afd:
+            sh.update(var_o=rd, surprise_o=((R,), _F32), sterm=rd)
+        if b.use_pred:
+            sh["pred_o"] = rd
+        if b.rt:
+            sh.update(radius_o=((R,), _F32), radius_var_o=((R,), _F32), ynorm=((R,), _F32))
+        if rt.enable_precision_routed_messages:
+            sh.update(msg=((E, d), _F32), keyv=((E, d), _F32), q=rd, wgt=((E,), _F32))
+        return sh
+
+    def _get_arena(self, device, steps: int) -> StepArena:
+        m = self.model
+        key = (device, m.R, m.d, m.router.E, m.bank.afd, m.bank.rt, m.bank.use_pred,
+               m.router.enable_precision_routed_messages)
+        if self._arena is None or self._arena_key != key:
+            self._arena = StepArena(self._shapes(), chunk_steps=max(128, 4 * steps))
+            self._arena_key = key
+            self._ws = None
+        return self._arena
+
+    def _workspace(self, device):
+        """Backward scratch shared by all steps (the stream serialises them)."""
+        if self._ws is not None and self._ws["gM"].device == device:
+            return self._ws
+        m = self.model
+        R, d, E = m.R, m.d, max(m.router.E, 1)
+        ns = ops.bwd_nslab(d)
+        z = lambda *s: torch.zeros(*s, device=device)
+        ws = {"gM": z(R, d), "ghpre": z(R, d), "gy": z(R, d), "slab": z(ns, R, d), "slab_rt": z(ns, R),
+              "gH_tmp": z(R, d), "gHd": z(R, d), "rslab": z(ns, E, d), "slab_q": z(ns, R, d)}
+        for side in ("a", "b"):
+            for k in ("gnum", "gden", "gvar", "gpred"):
+                ws[f"{k}_{side}"] = z(R, d)
+            for k in ("gradius", "gradius_var"):
+                ws[f"{k}_{side}"] = z(R)
+        ws["_ptr"] = {k: t.data_ptr() for k, t in ws.items()}
+        self._ws = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def run(self, tokens, K_inner, focus_map, reg_mask_prev, H_prev):
+        """Same contract as CortexReasoner.reasoning_loop: (H_cur, reg_mask, last_logits, traces)."""
+        m = self.model
+        cfg, bank, router, gate = m.cfg, m.bank, m.router, m.gate
+        dev = H_prev.device
+        R, d, E = m.R, m.d, router.E
+        grad = torch.is_grad_enabled()
+        L = lib()
+        st = stream_handle()
+        if bank.S != 1 or bank.num.device != dev:
+            bank.flat.reflat()
+            bank.reset_state(dev, 1)
+        n_max = K_inner * (1 if cfg.train_deterministic_inner_loop else cfg.B_br)
+        arena = self._get_arena(dev, n_max)
+        if not grad:
+            arena.reset()  # nothing is kept from a no-grad loop: outputs are cloned below
+        chunk, i0 = arena.reserve(max(1, n_max), dev)
+        CP, CS = chunk.ptr, chunk.stride
+
+        sensor = m.sensor_vector(tokens, focus_map)
+        sens_c = sensor.detach().contiguous()
+        ebias = router._cached_bias(m.reg_coords)
+        ebias_c = ebias.detach().contiguous()
+        norm_in_w = m.norm_in.weight
+        tables = router._edge_tables(m.reg_coords)
+        rP, bP = router._params(), bank.params()
+        kw_k, kw_soft, kw_temp = bank.kwta_now()
+        flags = bank._flags(kw_soft, bank.cells[0].disable_kwta, True)
+        focus_any = (focus_map.any().to(_U8).reshape(1) if focus_map.numel() > 0
+                     else torch.ones(1, dtype=_U8, device=dev))
+        H0 = H_prev.detach().contiguous().float()
+        mask0 = reg_mask_prev.to(_U8).contiguous()
+        off, nbr = gate._tables(dev)
+
+        # ---- structs: everything static is set once per loop
+        ga = new("ic_gate_args", S=1, R=R, d=d, sensor_idx=m.io_idxs["sensor"], motor_idx=m.io_idxs["motor"],
+                 force_io=1, w1=gate.w1, w2=gate.w2, w3=gate.w3, w4=gate.w4, gain_ema=gate.gain_ema,
+                 homeo=gate.homeo, focus_any=focus_any, nbr_off=off, nbr=nbr)
+        rspec = ops.RouterSpec(R, d, E, router.nW, router.enable_precision_routed_messages)
+        ra = ops._router_args(rspec, tables, rP, 1)
+        ra.ebias = ebias_c.data_ptr()
+        P = dict(bP)
+        P["norm_in_w"] = norm_in_w
+        fa = ops._region_args(bank.spec, P, 1, 0.0, kw_k, flags, kw_temp)
+        fa.sensor = sens_c.data_ptr()
+        fa.last_dir, fa.last_norm = bank.last_dir.data_ptr(), bank.last_norm.data_ptr()
+        prec, afd, rt_, use_pred = rspec.precision, bank.afd, bank.rt, bank.use_pred
+        g_scores, g_select = L.ic_gate_scores, L.ic_gate_select
+        r_fwd, p_fwd = L.ic_router_fwd, L.ic_region_phase_fwd
+        ga_ref, ra_ref, fa_ref = ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(fa)
+        w5, w6 = gate.w5, gate.w6
+
+        # state pointers before the first step: the bank's own tensors (kept alive in `init`)
+        init = dict(num=bank.num, den=bank.den, var=bank.var, pred=bank.pred, radius=bank.radius,
+                    radius_var=bank.radius_var, surprise=bank.surprise, dt=bank.dt)
+        init = {k: v.detach().contiguous() for k, v in init.items()}
+        state = {k: v.data_ptr() for k, v in init.items()}
+        out_names = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o")]
+        if afd:
+            out_names += [("var", "var_o"), ("surprise", "surprise_o")]
+        if use_pred:
+            out_names += [("pred", "pred_o")]
+        if rt_:
+            out_names += [("radius", "radius_o"), ("radius_var", "radius_var_o")]
+        saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
+            + (["sterm"] if afd else [])
+        rsaved = ["msg", "keyv", "q", "wgt"] if prec else []
+        denom = float(max(1, cfg.K_inner - 1))
+        parent: List[int] = []
+        step_pos_l: List[float] = []
+
+        def step(par: int, step_k: int, u_mean: float, burst: int) -> int:
+            """One inner step whose H input is the output of step `par` (-1: the loop's H_prev)."""
+            i = len(parent)
+            a = i0 + i
+            if par < 0:
+                h_in, mk_in = H0.data_ptr(), mask0.data_ptr()
+            else:
+                h_in, mk_in = CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
+            mask_p = CP["mask"] + a * CS["mask"]
+            ga.H, ga.t5, ga.t6 = h_in, w5 * float(gate.value_bias), w6 * float(u_mean)
+            ga.k_total = max(0, cfg.k_active + burst)
+            ga.scores, ga.mask = CP["scores"] + a * CS["scores"], mask_p
+            rc = g_scores(ga_ref, st) or g_select(ga_ref, st)
+            if rc:
+                check(rc, "ic_gate")
+            M_p = CP["M"] + a * CS["M"]
+            if E > 0:
+                ra.H, ra.mask_prev, ra.M = h_in, mk_in, M_p
+                for k in rsaved:
+                    setattr(ra, k, CP[k] + a * CS[k])
+                rc = r_fwd(ra_ref, st)
+                if rc:
+                    check(rc, "ic_router_fwd")
+            # (E == 0: M stays at the zeros the arena was created with)
+            sp = float(step_k) / denom
+            fa.step_pos, fa.M, fa.mask = sp, M_p, mask_p
+            fa.num, fa.den, fa.dt = state["num"], state["den"], state["dt"]
+            fa.var, fa.surprise = state["var"], state["surprise"]
+            fa.pred, fa.radius, fa.radius_var = state["pred"], state["radius"], state["radius_var"]
+            fa.H = CP["H"] + a * CS["H"]
+            for k, ko in out_names:
+                p = CP[ko] + a * CS[ko]
+                setattr(fa, ko, p)
+                state[k] = p
+            for k in saved:
+                setattr(fa, k, CP[k] + a * CS[k])
+            rc = p_fwd(fa_ref, st)
+            if rc:
+                check(rc, "ic_region_phase_fwd")
+            parent.append(par)
+            step_pos_l.append(sp)
+            m.counters["inner_steps"] += 1
+            return i
+
+        Hf, Mf = chunk.fields["H"], chunk.fields["mask"]
+        H_of = lambda i: Hf[i0 + i] if i >= 0 else H0
+        mask_of = lambda i: Mf[i0 + i] if i >= 0 else mask0
+        Sf, surprise0 = chunk.fields.get("surprise_o"), init["surprise"][0]
+        surp_of = lambda i: Sf[i0 + i] if (Sf is not None and i >= 0) else surprise0
+        m._loop_cache = None
+        m._in_loop = True
+        try:
+            with torch.no_grad():
+                best, last_logits, traces = self._drive(step, H_of, mask_of, surp_of, K_inner, dev)
+        finally:
+            m._in_loop = False
+            m._loop_cache = None
+        n = len(parent)
+
+        # ---- hand the state back to the bank (copies: the arena is recycled at the next pass)
+        last = i0 + n - 1
+        f = chunk.fields
+        if n > 0:
+            bank.num, bank.den, bank.dt = f["num_o"][last:last + 1].clone(), f["den_o"][last:last + 1].clone(), \
+                f["dt_o"][last:last + 1].clone()
+            if afd:
+                bank.var, bank.surprise = f["var_o"][last:last + 1].clone(), f["surprise_o"][last:last + 1].clone()
+            if use_pred:
+                bank.pred = f["pred_o"][last:last + 1].clone()
+            if rt_:
+                bank.radius, bank.radius_var = f["radius_o"][last:last + 1].clone(), f["radius_var_o"][last:last + 1].clone()
+            if prec:
+                router._last_wgt = f["wgt"][last:last + 1, :E].clone()
+        if m._units is not None and E > 0 and n > 0:
+            self._count_units(chunk, i0, parent, mask0)
+
+        reg_mask = mask_of(best).bool()
+        if grad and n > 0:
+            s = _Sample()
+            s.chunk, s.i0, s.n, s.parent, s.best, s.step_pos = chunk, i0, n, parent, best, step_pos_l
+            s.init, s.H0, s.mask0, s.sensor, s.ebias, s.norm_in_w = init, H0, mask0, sens_c, ebias_c, norm_in_w
+            s.flags, s.kwta_k, s.kwta_temp = flags, kw_k, kw_temp
+            s.keep = (focus_any, tables, rP, bP)
+            H_cur = LoopFn.apply(sensor, ebias, norm_in_w, bank.anchor(dev), self, s)
+        else:
+            H_cur = H_of(best).clone()
+        return H_cur, reg_mask, last_logits, traces
+
+    def _count_units(self, chunk, i0, parent, mask0) -> None:
+        m = self.model
+        n = len(parent)
+        masks = chunk.fields["mask"][i0:i0 + n].float()
+        allm = torch.cat([mask0.float().reshape(1, -1), masks], 0)
+        prev = allm[torch.tensor([p + 1 for p in parent], device=masks.device)]  # [n,R]
+        ea = prev[:, m.router.src_idx]  # [n,E]
+        into = torch.zeros(n, m.R, device=masks.device).index_add_(1, m.router.dst_idx, ea)
+        m._units += torch.stack([masks.sum(), ea.sum(), (into > 0).sum().float()])
+
+    def _drive(self, step, H_of, mask_of, surp_of, K_inner, dev):
+        """The control flow of reference model.py:329-460 over step ids (no autograd)."""
+        m = self.model
+        cfg, gate = m.cfg, m.gate
+        last_logits = torch.zeros(m.V, device=dev)
+        traces: List[torch.Tensor] = []
+        if cfg.train_deterministic_inner_loop:
+            cur = -1
+            for k in range(K_inner):
+                u_mean = float(1.0 - F.softmax(last_logits, dim=-1).max()) if k > 0 else 0.0
+                gate.value_bias = 0.0
+                cur = step(cur, k, u_mean, 0)
+                last_logits = m._heads(H_of(cur), mask_of(cur))[0]
+                traces.append(H_of(cur).clone())
+            return cur, last_logits, traces
+
+        B_br = cfg.B_br
+        motor = m.io_idxs["motor"]
+        branches = [(m.work.slots.clone(), -1) for _ in range(B_br)]  # (workspace slots, step id of H/mask)
+        scores = [torch.tensor(-1e9, device=dev) for _ in range(B_br)]
+        prev = -1
+        for k in range(K_inner):
+            H_prev, on = H_of(prev), mask_of(prev).float()
+            ws_prev = (H_prev * on.unsqueeze(-1)).sum(0) / on.sum().clamp_min(1.0)
+            _p, g = m.plan(ws_prev, H_prev[motor])
+            v = m.critic(ws_prev, g).reshape(1)
+            if k > 0:
+                u = (1.0 - F.softmax(last_logits, dim=-1).max()).reshape(1)
+                u_mean, v_hat = torch.cat([u, v]).tolist()  # one host sync for both steering scalars
+            else:
+                u_mean, v_hat = 0.0, float(v.item())
+            gate.value_bias = v_hat
+            burst = schedule_burst(u_mean, v_hat, m.R)
+            for b in range(B_br):
+                m.work.slots = branches[b][0].clone()
+                par = branches[b][1]
+                cur = step(par, k, u_mean, burst)
+                H_cur = H_of(cur)
+                logits, _rtd, _ws, motor_state = m._heads(H_cur, mask_of(cur))
+                ver_energy = m.verify(motor_state, F.softmax(logits, dim=-1), aux=m._verify_aux(dev, surp_of(cur)))
+                delta_g = goodness(H_cur) - goodness(H_of(par))
+                scores[b] = 0.6 * delta_g + 0.2 * (-ver_energy) + 0.2 * context_logprob(logits)
+                branches[b] = (m.work.slots, cur)
+                last_logits = logits
+            top = torch.topk(torch.stack(scores), k=min(B_br, 2)).indices.tolist()
+            branches = [branches[i] for i in top]
+            scores = [scores[i] for i in top]
+            traces.append(H_of(branches[0][1]).clone())
+            if should_halt(scores, u_mean, k, K_inner):
+                break
+            m.work.slots, prev = branches[0]
+        best = int(torch.stack(scores).argmax().item())
+        m.work.slots, cur = branches[best]
+        return cur, last_logits, traces
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, s: _Sample, gH_final: torch.Tensor):
+        m = self.model
+        bank, router = m.bank, m.router
+        dev = gH_final.device
+        R, d, E = m.R, m.d, router.E
+        Ez = max(E, 1)
+        L = lib()
+        st = stream_handle()
+        bank.coord.begin()
+        ws = self._workspace(dev)
+        WP = ws["_ptr"]
+        ns = ops.bwd_nslab(d)
+        n_r = s.best + 1  # steps after the winning one feed nothing that reaches the loss
+        flags = s.flags
+        afd, rt_, use_pred = bool(flags & ops.IC_F_AFD), bool(flags & ops.IC_F_RT), bool(flags & ops.IC_F_PRED)
+        prec = router.enable_precision_routed_messages
+        chunk, i0 = s.chunk, s.i0
+        CP, CS = chunk.ptr, chunk.stride
+
+        # ---- per-loop zero block: everything the kernels only write for active rows
+        zf = {"gH": R * d, "g_norm_w_rows": R * d, "g_raw_decay_rows": R * d, "g_norm_in_rows": R * d, "gsens": 2 * d,
+              "g_ebias_part": ns * Ez}
+        if afd:
+            zf.update(g_pn_rows=R * d, g_on_rows=R * d)
+        if rt_:
+            zf["g_rnoise_rows"] = R * 2
+        if prec:
+            zf["g_rawP_rows"] = Ez * d
+        Z, zp = {}, {}
+        for k, sz in zf.items():
+            Z[k] = torch.zeros(n_r, sz, device=dev)
+            zp[k] = Z[k].data_ptr()
+        Z["gH"][s.best].copy_(gH_final.reshape(-1))
+        has_grad = [False] * n_r
+        has_grad[s.best] = True
+
+        # ---- tape slots for the deferred weight gradients
+        tape = bank.tape
+        t0 = tape.alloc_n(n_r, dev)
+        tape.buf["mask"][t0:t0 + n_r, 0].copy_(chunk.fields["mask"][i0:i0 + n_r])
+        tape.visited[t0:t0 + n_r].fill_(1)
+        TB = {k: (tape.buf[k].data_ptr(), tape.buf[k].stride(0) * 4) for k in ("g", "x", "o")}
+        if E > 0:
+            rtape = router._get_tape(1, dev)
+            rt0 = rtape.alloc_n(n_r, dev)
+            rtape.visited[rt0:rt0 + n_r].fill_(1)
+            RB = {k: (rtape.buf[k].data_ptr(), rtape.buf[k].stride(0) * rtape.buf[k].element_size())
+                  for k in rtape.buf}
+
+        # ---- structs
+        tables, rP, bP = s.keep[1], s.keep[2], s.keep[3]
+        P = dict(bP)
+        P["norm_in_w"] = s.norm_in_w
+        b = new("ic_region_bwd_args")
+        b.f = ops._region_args(bank.spec, P, 1, 0.0, s.kwta_k, flags, s.kwta_temp)
+        b.f.sensor = s.sensor.data_ptr()
+        b.gM, b.ghpre, b.gy, b.slab, b.slab_rt = WP["gM"], WP["ghpre"], WP["gy"], WP["slab"], WP["slab_rt"]
+        rb = new("ic_router_bwd_args")
+        rspec = ops.RouterSpec(R, d, E, router.nW, prec)
+        if E > 0:
+            rb.f = ops._router_args(rspec, tables, rP, 1)
+            rb.f.ebias = s.ebias.data_ptr()
+            rb.f.M = WP["gM"]  # unused by the backward, must be non-NULL
+            rb.gM = WP["gM"]
+            rb.src_off, rb.src_edges = tables["src_off"].data_ptr(), tables["src_edges"].data_ptr()
+            rb.slab, rb.gHd, rb.slab_q = WP["rslab"], WP["gHd"], WP["slab_q"]
+        b_ref, rb_ref = ctypes.byref(b), ctypes.byref(rb)
+        p_bwd, r_bwd = L.ic_region_phase_bwd, L.ic_router_bwd
+        saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
+            + (["sterm"] if afd else [])
+        rsaved = ["msg", "keyv", "q", "wgt"] if prec else []
+        init = {k: v.data_ptr() for k, v in s.init.items()}
+        state_in = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o")] + ([("var", "var_o")] if afd else []) \
+            + ([("pred", "pred_o")] if use_pred else []) \
+            + ([("radius", "radius_o"), ("radius_var", "radius_var_o")] if rt_ else [])
+        gnames = ["gnum", "gden"] + (["gvar"] if afd else []) + (["gpred"] if use_pred else []) \
+            + (["gradius", "gradius_var"] if rt_ else [])
+        rows = ["g_norm_w_rows", "g_raw_decay_rows", "g_norm_in_rows"] + (["g_pn_rows", "g_on_rows"] if afd else []) \
+            + (["g_rnoise_rows"] if rt_ else [])
+        side, have_state_grad = "a", False
+        H0p, mask0p = s.H0.data_ptr(), s.mask0.data_ptr()
+        for t in range(n_r - 1, -1, -1):
+            a = i0 + t
+            f = b.f
+            f.step_pos = s.step_pos[t]
+            f.M, f.mask = CP["M"] + a * CS["M"], CP["mask"] + a * CS["mask"]
+            for k, ko in state_in:  # the step's input state = the previous step's output
+                setattr(f, k, init[k] if t == 0 else CP[ko] + (a - 1) * CS[ko])
+            if rt_:
+                f.radius_o = CP["radius_o"] + a * CS["radius_o"]
+            for k in saved:
+                setattr(f, k, CP[k] + a * CS[k])
+            b.gH = zp["gH"] + t * R * d * 4
+            other = "b" if side == "a" else "a"
+            for g in gnames:
+                setattr(b, g + "_o", WP[f"{g}_{side}"] if have_state_grad else None)
+                setattr(b, g, WP[f"{g}_{other}"])
+            b.gsens = zp["gsens"] + t * 2 * d * 4
+            for k in rows:
+                setattr(b, k, zp[k] + t * zf[k] * 4)
+            for k, fld in (("g", "tape_g"), ("x", "tape_x"), ("o", "tape_o")):
+                setattr(b, fld, TB[k][0] + (t0 + t) * TB[k][1])
+            rc = p_bwd(b_ref, st)
+            if rc:
+                check(rc, "ic_region_phase_bwd")
+            side, have_state_grad = other, True
+            if E == 0:
+                continue
+            par = s.parent[t]
+            rf = rb.f
+            if par < 0:
+                rf.H, rf.mask_prev = H0p, mask0p
+            else:
+                rf.H, rf.mask_prev = CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
+            for k in rsaved:
+                setattr(rf, k, CP[k] + a * CS[k])
+            direct = par >= 0 and not has_grad[par]
+            rb.gH = zp["gH"] + par * R * d * 4 if direct else WP["gH_tmp"]
+            rb.g_ebias_part = zp["g_ebias_part"] + t * ns * Ez * 4
+            if prec:
+                rb.g_rawP_rows = zp["g_rawP_rows"] + t * Ez * d * 4
+            for k, fld in (("gmsg", "tape_gmsg"), ("H", "tape_H"), ("eact", "tape_eact"), ("gkey", "tape_gkey"),
+                           ("gq", "tape_gq"), ("qact", "tape_qact")):
+                if k in RB:
+                    setattr(rb, fld, RB[k][0] + (rt0 + t) * RB[k][1])
+            rc = r_bwd(rb_ref, st)
+            if rc:
+                check(rc, "ic_router_bwd")
+            if par >= 0:
+                if not direct:
+                    Z["gH"][par].add_(ws["gH_tmp"].reshape(-1))
+                has_grad[par] = True
+
+        # ---- small parameter gradients: one reduction per loop
+        sink = bank._grad_sink(0)
+        sink("norm_w", Z["g_norm_w_rows"].sum(0).view(R, d))
+        sink("raw_decay", Z["g_raw_decay_rows"].sum(0).view(R, d))
+        if afd:
+            if flags & ops.IC_F_NOISE_VEC:
+                sink("pn_param", Z["g_pn_rows"].sum(0).view(R, d))
+                sink("on_param", Z["g_on_rows"].sum(0).view(R, d))
+            else:
+                sink("pn_param", Z["g_pn_rows"].view(n_r, R, d).sum((0, 2)))
+                sink("on_param", Z["g_on_rows"].view(n_r, R, d).sum((0, 2)))
+        if rt_:
+            rn = Z["g_rnoise_rows"].sum(0).view(R, 2)
+            sink("rpn_param", rn[:, 0].contiguous())
+            sink("ron_param", rn[:, 1].contiguous())
+        g_ebias = None
+        if E > 0:
+            g_ebias = Z["g_ebias_part"].view(n_r * ns, Ez).sum(0)[:E]
+            if prec:
+                router._grad_sink("raw_P", Z["g_rawP_rows"].sum(0).view(Ez, d)[:E], tables["widx_long"])
+        g_sensor = Z["gsens"].view(n_r * 2, d).sum(0)
+        g_norm_in = Z["g_norm_in_rows"].view(n_r * R, d).sum(0)
+        return g_sensor, g_ebias, g_norm_in
+
+
+class LoopFn(torch.autograd.Function):
+    """One autograd node per reasoning loop: forward hands out the loop's final region states
+    (already computed by LoopEngine.run), backward replays the recorded steps in reverse."""
+
+    @staticmethod
+    def forward(ctx, sensor, ebias, norm_in_w, anchor, engine, sample):
+        ctx.engine, ctx.sample = engine, sample
+        ctx.shapes = (sensor.shape, ebias.shape)
+        return sample.chunk.fields["H"][sample.i0 + sample.best].clone()
+
+    @staticmethod
+    def backward(ctx, gH):
+        g_sensor, g_ebias, g_norm_in = ctx.engine.backward(ctx.sample, gH.contiguous())
+        sshape, eshape = ctx.shapes
+        if g_ebias is None:
+            g_ebias = torch.zeros(eshape, device=gH.device)
+        return g_sensor.view(sshape), g_ebias.view(eshape), g_norm_in, None, None, None

@@ -7,6 +7,7 @@ gradients are deferred to one ic_*_wgrad launch per backward pass through a tape
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -102,6 +103,16 @@ class Tape:
         self.pos += 1
         return t
 
+    def alloc_n(self, n: int, device) -> int:
+        """n consecutive slots (the LoopEngine books a whole loop at once)."""
+        if self.visited is not None and self.visited.device != device:
+            self.cap, self.pos = 0, 0
+        if self.pos + n > self.cap:
+            self._grow(device, self.pos + n)
+        t = self.pos
+        self.pos += n
+        return t
+
     def slot(self, name: str, t: int) -> torch.Tensor:
         return self.buf[name][t]
 
@@ -109,6 +120,10 @@ class Tape:
         if self.pos:
             self.visited[: self.pos].zero_()
         self.pos = 0
+
+
+# rows of W per workgroup in the forward GEMVs (0 = library default); a tuning knob for the sweeps
+ROWS_FWD = int(os.environ.get("IC_ROWS_FWD", "0"))
 
 
 def _z(like: torch.Tensor, *shape, dtype=None) -> torch.Tensor:
@@ -132,7 +147,7 @@ class RegionPhaseSpec:
 def _region_args(spec: RegionPhaseSpec, P: Dict[str, torch.Tensor], S: int, step_pos: float, kwta_k: int,
                  flags: int, kwta_temp: float):
     a = new("ic_region_args", S=S, R=spec.R, d=spec.d, m_time=spec.m_time, kwta_k=kwta_k, flags=flags,
-            sensor_idx=spec.sensor_idx, motor_idx=spec.motor_idx, rows_fwd=0, step_pos=float(step_pos),
+            sensor_idx=spec.sensor_idx, motor_idx=spec.motor_idx, rows_fwd=ROWS_FWD, step_pos=float(step_pos),
             kwta_temp=float(kwta_temp), pred_alpha=float(spec.pred_alpha))
     for k in ("W", "norm_w", "raw_decay", "norm_in_w", "W_time", "pn_param", "on_param", "rpn_param", "ron_param"):
         t = P.get(k)

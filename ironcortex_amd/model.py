@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from .config import CortexConfig
 from .constants import EPS_DIV
 from .energy import EnergyVerifierHead
+from .engine import LoopEngine
 from .gate import Gate, Router
 from .heads import CriticHead, PlannerHead, RTDHead, TokenHead_MFS, Workspace
 from .hip import ops
@@ -88,6 +89,10 @@ class CortexReasoner(nn.Module):
         self._loop_cache = None
         self._in_loop = False
         self._heads_used = None
+        # True while a caller (train_step) promises not to back-propagate through the inner-step
+        # logits / workspace: the loop then runs on the LoopEngine (engine.py)
+        self._logits_detached = False
+        object.__setattr__(self, "engine", LoopEngine(self))
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, recurse=True):
@@ -207,7 +212,14 @@ class CortexReasoner(nn.Module):
             into = torch.zeros(self.R, device=dev).index_add_(0, self.router.dst_idx, ea)
             self._units += torch.stack([mask.sum().float(), ea.sum(), (into > 0).sum().float()])
         # 4) heads on motor & workspace -- no host sync: the active set stays on the device
-        reg_mask = mask[0].bool()
+        logits, rtd_logits, ws_state, motor_state = self._heads(H_cur, mask[0])
+        return H_cur, mask[0].bool(), logits, rtd_logits, ws_state, motor_state
+
+    def _heads(self, H_cur: torch.Tensor, mask_u8: torch.Tensor):
+        """Workspace write + token / RTD heads of one inner step (model.py:296-321) for H_cur [R,d]
+        and the uint8 active mask [R] -> (logits [V], rtd_logits [2], ws_state [d], motor_state [d])."""
+        dev = H_cur.device
+        reg_mask = mask_u8.bool()
         on = reg_mask.to(H_cur.dtype)
         motor = self.io_idxs["motor"]
         motor_state = H_cur[motor]
@@ -226,11 +238,12 @@ class CortexReasoner(nn.Module):
         w = on.clone()
         w[motor] = 0.0
         logits = (motor_logits + (w.unsqueeze(-1) * per_region).sum(0)) / (1.0 + w.sum())
-        if self._heads_used is None or self._heads_used.device != dev:
-            self._heads_used = torch.zeros(self.R, dtype=torch.bool, device=dev)
-        self._heads_used |= w.bool()
+        if torch.is_grad_enabled():
+            if self._heads_used is None or self._heads_used.device != dev:
+                self._heads_used = torch.zeros(self.R, dtype=torch.bool, device=dev)
+            self._heads_used |= w.bool()
         rtd_logits = self.rtdd(motor_state)
-        return H_cur, reg_mask, logits, rtd_logits, ws_state, motor_state
+        return logits, rtd_logits, ws_state, motor_state
 
     def _head_cache(self):
         """Stacked views of the token heads, rebuilt once per reasoning loop (the parameters do
@@ -260,12 +273,13 @@ class CortexReasoner(nn.Module):
     def zeros_state(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
         return torch.zeros(self.R, self.d, device=device), torch.zeros(self.R, dtype=torch.bool, device=device)
 
-    def _verify_aux(self, device) -> Optional[torch.Tensor]:
+    def _verify_aux(self, device, surprise: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         if not self.cfg.enable_ff_energy_alignment:
             return None
         ent = getattr(self.local_mix.attn, "last_attn_entropy", torch.tensor(0.0, device=device))
+        surprise = self.bank.surprise[0] if surprise is None else surprise
         return torch.stack([self.local_mix.last_energy.detach().to(device),
-                            self.bank.surprise[0].mean().to(device), ent.detach().to(device)])
+                            surprise.mean().to(device), ent.detach().to(device)])
 
     # ------------------------------------------------------------------ reasoning loop
     def reasoning_loop(self, tokens: torch.Tensor, K_inner: int, focus_map: torch.Tensor,
@@ -273,9 +287,11 @@ class CortexReasoner(nn.Module):
         """plan -> critic -> gate; branch; verify; halt (model.py:329-460)."""
         self._sensor_cache = None
         self._loop_cache = None
-        self._in_loop = True
         self.router.begin_loop()
         try:
+            if self.engine.usable(H_prev, not self._logits_detached):
+                return self.engine.run(tokens, K_inner, focus_map, reg_mask_prev, H_prev)
+            self._in_loop = True
             return self._reasoning_loop(tokens, K_inner, focus_map, reg_mask_prev, H_prev)
         finally:
             self._in_loop = False

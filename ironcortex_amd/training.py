@@ -65,7 +65,14 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     neg_tokens, focus_neg, d_targets, d_masks, is_real = make_negatives(clean_tokens, model.V)
     tokens_all = torch.cat([clean_tokens, neg_tokens], dim=0)
     focus_all = torch.cat([torch.zeros_like(focus_neg, dtype=torch.bool), focus_neg], dim=0)
-    H_all, reg_all, logits_all, _tr, energy_all, entropy_all = model.reasoning_loop_batch(tokens_all, cfg.K_inner, focus_all)
+    # no loss below back-propagates through the inner-step logits / workspace (training.py:120-231):
+    # the loops may run on the LoopEngine (one autograd node per loop)
+    model.engine.reset()
+    model._logits_detached = True
+    try:
+        H_all, reg_all, logits_all, _tr, energy_all, entropy_all = model.reasoning_loop_batch(tokens_all, cfg.K_inner, focus_all)
+    finally:
+        model._logits_detached = False
     H_pos, H_neg = H_all[:B], H_all[B:]
     mask_p, mask_n = reg_all[:B], reg_all[B:]
     logits_pos, logits_neg = logits_all[:B], logits_all[B:]

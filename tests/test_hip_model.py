@@ -26,10 +26,13 @@ def build(cfg, sd):
     return model.to(DEV)
 
 
+@pytest.mark.parametrize("engine", [True, False], ids=["engine", "general"])
 @pytest.mark.parametrize("name", list(MODEL_CASES))
-def test_reasoning_loop_vs_reference(name):
+def test_reasoning_loop_vs_reference(name, engine):
+    """engine: the LoopEngine (ironcortex_amd/engine.py); general: one autograd Function per call."""
     gold, cfg, sd, tokens, focus = load_case(name)
     model = build(cfg, sd)
+    model.engine.enabled = engine
     with torch.no_grad():
         H, m, logits, traces, en, ent = model.reasoning_loop_batch(tokens.to(DEV), cfg.K_inner, focus.to(DEV))
     assert np.array_equal(m.cpu().numpy(), gold["loop.mask"])
@@ -42,11 +45,13 @@ def test_reasoning_loop_vs_reference(name):
     close(model.regions[0].state_num, gold["loop.num"][0])
 
 
+@pytest.mark.parametrize("engine", [True, False], ids=["engine", "general"])
 @pytest.mark.parametrize("name", list(MODEL_CASES))
-def test_two_train_steps_vs_reference(name):
+def test_two_train_steps_vs_reference(name, engine):
     import ironcortex_amd as ic
     gold, cfg, sd, tokens, focus = load_case(name)
     model = build(cfg, sd)
+    model.engine.enabled = engine
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     seed_train()
     for step in range(2):
