@@ -277,6 +277,74 @@ int ic_hebbian_rank1(float* W, const int32_t* dst_of_edge, const int32_t* src, c
                      const float* coef, const float* H, int32_t B, int32_t R, int32_t d, int32_t E,
                      ic_stream_t stream);
 
+/* ------------------------------------------------------------------ loop heads (forward only)
+ * The small heads that steer the reasoning loop but never carry a gradient in train_step or
+ * generation (reference model.py:296-321,376-438).  One C call per inner step instead of ~40
+ * ATen dispatches.  Callers that need d(logits)/d(params) use the PyTorch modules instead. */
+enum { IC_ACT_NONE = 0, IC_ACT_GELU = 1, IC_ACT_SILU = 2 };
+
+/* y = act(W . LN(cat(x0,x1,x2)) + b): nn.Linear on a vector (heads.py:39-46 MLP, energy.py:12-30
+ * EnergyVerifierHead incl. its leading LayerNorm).  GELU is the exact erf form, LayerNorm the
+ * biased-variance form of torch.nn.LayerNorm. */
+typedef struct ic_gemv_desc {
+  const float* W;    /* [rows, n0+n1+n2] row-major (nn.Linear.weight) */
+  const float* b;    /* [rows] or NULL */
+  const float* ln_g; /* [n0+n1+n2] LayerNorm weight/bias applied to the input first, or NULL */
+  const float* ln_b;
+  const float *x0, *x1, *x2; /* input segments (torch.cat order); unused ones have n = 0 */
+  float* y;          /* [rows] */
+  int32_t n0, n1, n2;
+  int32_t rows, act; /* IC_ACT_* */
+  float ln_eps;
+} ic_gemv_desc;
+/* descs is a HOST array; the n GEMVs run in order on the stream (each may read the previous y). */
+int ic_gemv_chain(const ic_gemv_desc* descs, int32_t n, ic_stream_t stream);
+
+/* Workspace write + token logits of one inner step (model.py:296-318, heads.py:26-29,96-119):
+ *   slots_out = KWTA(slots_in + delta, d/4), delta[j] = H of the j-th active region (index order);
+ *   logits = (MFS(H[motor]) + sum_{r active, r != motor} region_head_r(H[r])) / (1 + #such r);
+ * plus the loop's steering statistics of those logits and states. */
+typedef struct ic_heads_args {
+  int32_t R, d, V, Kf, n_slots, motor_idx, kwta_k;
+  const float* H;        /* [R,d] this step's region states */
+  const float* H_par;    /* [R,d] the states the step started from */
+  const uint8_t* mask;   /* [R] active regions of this step */
+  const float* slots_in; /* [n_slots,d] */
+  float* slots_out;      /* [n_slots,d] */
+  const float* lm_gate_W; /* [Kf,d]  TokenHead_MFS.gate (heads.py:99) */
+  const float* lm_gate_b; /* [Kf] */
+  const float* lm_W;     /* [Kf,V,d] the Kf facets (heads.py:100) */
+  const float* lm_b;     /* [Kf,V] */
+  const float* rh_W;     /* [R,V,d] region_heads */
+  const float* rh_b;     /* [R,V] */
+  const float* surprise; /* [R] surprise_ema after this step, or NULL */
+  float* z;              /* [Kf + Kf*V] scratch: gate pre-activations, then facet outputs */
+  float* per_region;     /* [R,V] scratch */
+  float* logits;         /* [V] */
+  float* probs;          /* [V] softmax(logits) */
+  float* stats;          /* [4] u = 1 - max p (utils.py:127-130); sum p log(p+1e-12) (utils.py:133-137);
+                                goodness(H) - goodness(H_par) (model.py:430); mean surprise */
+  float* aux_surprise;   /* where the verifier's aux vector wants mean surprise, or NULL */
+} ic_heads_args;
+int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
+
+/* score = 0.6*stats[2] + 0.2*(-energy) + 0.2*stats[1]   (model.py:431-438) */
+int ic_branch_score(const float* stats, const float* energy, float* score, ic_stream_t stream);
+
+/* Start of an outer iteration (model.py:371-386): among n_cand candidate states pick the one
+ * with the highest score (first on ties; scores NULL -> candidate 0) WITHOUT a host round trip,
+ * and form ws_prev = mean of its previously active rows (zeros when none) and its motor row,
+ * the inputs of the planner / critic chain. */
+typedef struct ic_steer_args {
+  int32_t R, d, n_cand, motor_idx;
+  const float* H_cand[8];       /* device pointers [R,d] */
+  const uint8_t* mask_cand[8];  /* device pointers [R] */
+  const float* scores;          /* [n_cand] device, or NULL */
+  float* ws_prev;               /* [d] */
+  float* motor;                 /* [d] */
+} ic_steer_args;
+int ic_steer_select(const ic_steer_args* a, ic_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks
  * No counterpart in the reference (its cfg.profile timers read perf_counter without a device
  * sync, model.py:219-294).  When enabled every kernel launch of this library is bracketed by

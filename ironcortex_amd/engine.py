@@ -28,10 +28,9 @@ import ctypes
 from typing import Dict, List, Optional, Tuple
 
 import torch
-import torch.nn.functional as F
 
-from .hip import check, lib, new, ops, stream_handle
-from .utils import context_logprob, goodness, schedule_burst, should_halt
+from .hip import CLASSES, ENUMS, check, lib, new, ops, stream_handle
+from .utils import schedule_burst, should_halt
 
 _F32, _I32, _U8 = torch.float32, torch.int32, torch.uint8
 
@@ -112,7 +111,8 @@ class LoopEngine:
         R, d, E = m.R, m.d, max(rt.E, 1)
         rd = ((R, d), _F32)
         sh = {"H": rd, "num_o": rd, "den_o": rd, "dt_o": ((R,), _I32), "M": rd, "scores": ((R,), _F32),
-              "mask": ((R,), _U8), "inv_s": ((R, 2), _F32)}
+              "mask": ((R,), _U8), "inv_s": ((R, 2), _F32), "logits": ((m.V,), _F32),
+              "slots": (tuple(m.work.slots.shape), _F32)}
         for k in ("x", "u1", "r_s", "k_s", "v_s", "y", "hpre", "gate"):
             sh[k] = rd
         if b.afd:
@@ -273,17 +273,16 @@ class LoopEngine:
         Hf, Mf = chunk.fields["H"], chunk.fields["mask"]
         H_of = lambda i: Hf[i0 + i] if i >= 0 else H0
         mask_of = lambda i: Mf[i0 + i] if i >= 0 else mask0
-        Sf, surprise0 = chunk.fields.get("surprise_o"), init["surprise"][0]
-        surp_of = lambda i: Sf[i0 + i] if (Sf is not None and i >= 0) else surprise0
-        m._loop_cache = None
-        m._in_loop = True
-        try:
-            with torch.no_grad():
-                best, last_logits, traces = self._drive(step, H_of, mask_of, surp_of, K_inner, dev)
-        finally:
-            m._in_loop = False
-            m._loop_cache = None
+        H0p, mask0p = H0.data_ptr(), mask0.data_ptr()
+        ptr_of = lambda i: ((CP["H"] + (i0 + i) * CS["H"], CP["mask"] + (i0 + i) * CS["mask"]) if i >= 0
+                            else (H0p, mask0p))
+        with torch.no_grad():
+            best, last_step, traces = self._drive(step, ptr_of, H_of, K_inner, dev, chunk, i0, H0, mask0)
         n = len(parent)
+        last_logits = (chunk.fields["logits"][i0 + last_step].clone() if last_step >= 0
+                       else torch.zeros(m.V, device=dev))
+        if best >= 0:
+            m.work.slots = chunk.fields["slots"][i0 + best].clone()
 
         # ---- hand the state back to the bank (copies: the arena is recycled at the next pass)
         last = i0 + n - 1
@@ -324,60 +323,162 @@ class LoopEngine:
         into = torch.zeros(n, m.R, device=masks.device).index_add_(1, m.router.dst_idx, ea)
         m._units += torch.stack([masks.sum(), ea.sum(), (into > 0).sum().float()])
 
-    def _drive(self, step, H_of, mask_of, surp_of, K_inner, dev):
-        """The control flow of reference model.py:329-460 over step ids (no autograd)."""
+    # ------------------------------------------------------------------ loop heads (HIP, no autograd)
+    def _heads_setup(self, dev):
+        """C structs + scratch for ic_heads_fwd / ic_gemv_chain / ic_steer_select, rebuilt when the
+        parameters move (device change, deepcopy, load into new storage)."""
+        m = self.model
+        hf = m._heads_flat
+        hf.reflat()  # no-op while every facet / region-head Parameter still views the arena
+        mods = [m.lm_head.gate]
+        if m.plan is not None:
+            mods += [m.plan.mlp_p.net[0], m.plan.mlp_p.net[2], m.plan.mlp_g.net[0], m.plan.mlp_g.net[2],
+                     m.critic.mlp.net[0], m.critic.mlp.net[2]]
+        if m.verify is not None:
+            mods += [m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]]
+        key = (dev, hf.flat.data_ptr()) + tuple(p.data_ptr() for l in mods for p in (l.weight, l.bias))
+        hs = getattr(self, "_hs", None)
+        if hs is not None and hs["key"] == key:
+            return hs
+        R, d, V, Kf = m.R, m.d, m.V, m.lm_head.Kf
+        z = lambda *s: torch.zeros(*s, device=dev)
+        buf = dict(z=z(Kf + Kf * V), per_region=z(R, V), probs=z(V), ls=z(64), aux=z(4), ws_prev=z(d), motor=z(d),
+                   p_h=z(d), p=z(d), g_h=z(2 * d), g=z(d), c_h=z(2 * d))
+        P = {k: t.data_ptr() for k, t in buf.items()}
+        ha = new("ic_heads_args", R=R, d=d, V=V, Kf=Kf, n_slots=m.work.slots.shape[0], motor_idx=m.io_idxs["motor"],
+                 kwta_k=max(1, d // 4), lm_gate_W=m.lm_head.gate.weight, lm_gate_b=m.lm_head.gate.bias,
+                 lm_W=hf.stacked("facet_W"), lm_b=hf.stacked("facet_b"), rh_W=hf.stacked("rh_W"),
+                 rh_b=hf.stacked("rh_b"), z=buf["z"], per_region=buf["per_region"], probs=buf["probs"])
+        G = CLASSES["ic_gemv_desc"]
+
+        def desc(g, lin_, xs, y, act, ln=None):
+            g.W, g.b = lin_.weight.data_ptr(), lin_.bias.data_ptr()
+            for i, (ptr_, n) in enumerate(xs):
+                setattr(g, f"x{i}", ptr_)
+                setattr(g, f"n{i}", n)
+            g.y, g.rows, g.act = y, lin_.weight.shape[0], act
+            if ln is not None:
+                g.ln_g, g.ln_b, g.ln_eps = ln.weight.data_ptr(), ln.bias.data_ptr(), ln.eps
+            assert lin_.weight.shape[1] == sum(n for _, n in xs) and lin_.weight.is_contiguous()
+
+        steer = None
+        if m.plan is not None:
+            steer = (G * 6)()
+            gelu, none = ENUMS["IC_ACT_GELU"], ENUMS["IC_ACT_NONE"]
+            desc(steer[0], mods[1], [(P["ws_prev"], d)], P["p_h"], gelu)             # heads.py:57-59
+            desc(steer[1], mods[2], [(P["p_h"], d)], P["p"], none)
+            desc(steer[2], mods[3], [(P["p"], d), (P["ws_prev"], d)], P["g_h"], gelu)
+            desc(steer[3], mods[4], [(P["g_h"], 2 * d)], P["g"], none)
+            desc(steer[4], mods[5], [(P["ws_prev"], d), (P["g"], d)], P["c_h"], gelu)  # heads.py:69-70
+            desc(steer[5], mods[6], [(P["c_h"], 2 * d)], P["ls"] + 40 * 4, none)
+        ver = None
+        if m.verify is not None:
+            ver = (G * 3)()
+            silu = ENUMS["IC_ACT_SILU"]
+            ln, l1, l2, l3 = m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]
+            hid = l1.weight.shape[0]
+            buf["h1"], buf["h2"] = z(hid), z(hid)
+            P["h1"], P["h2"] = buf["h1"].data_ptr(), buf["h2"].data_ptr()
+            desc(ver[0], l1, [(0, d), (P["probs"], V), (P["aux"], m.verify.aux_dim)], P["h1"], silu, ln)  # energy.py:17-30
+            desc(ver[1], l2, [(P["h1"], hid)], P["h2"], silu)
+            desc(ver[2], l3, [(P["h2"], hid)], 0, ENUMS["IC_ACT_NONE"])
+        sa = new("ic_steer_args", R=R, d=d, motor_idx=m.io_idxs["motor"], ws_prev=buf["ws_prev"], motor=buf["motor"])
+        self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods)
+        return self._hs
+
+    def _drive(self, step, ptr_of, H_of, K_inner, dev, chunk, i0, H0, mask0):
+        """The control flow of reference model.py:329-460 over step ids, heads on the HIP library."""
         m = self.model
         cfg, gate = m.cfg, m.gate
-        last_logits = torch.zeros(m.V, device=dev)
+        L, st = lib(), stream_handle()
+        hs = self._heads_setup(dev)
+        ha, ver, steer, sa, P, ls = hs["ha"], hs["ver"], hs["steer"], hs["sa"], hs["P"], hs["buf"]["ls"]
+        ha_ref, sa_ref = ctypes.byref(ha), ctypes.byref(sa)
+        d, motor = m.d, m.io_idxs["motor"]
+        CP, CS = chunk.ptr, chunk.stride
+        afd = "surprise_o" in CP
+        aux_on = ver is not None and m.verify.aux_dim > 0
+        if aux_on:  # model.py:396-404: [mixer energy, mean surprise (written per step), attention entropy]
+            ent = getattr(m.local_mix.attn, "last_attn_entropy", None)
+            aux = hs["buf"]["aux"]
+            aux[0] = m.local_mix.last_energy.detach()
+            aux[2] = ent.detach() if ent is not None else 0.0
+            ha.aux_surprise = P["aux"] + 4
+        else:
+            ha.aux_surprise = None
+        slots0 = m.work.slots.detach().contiguous()
+        slots_ptr = lambda i: CP["slots"] + (i0 + i) * CS["slots"] if i >= 0 else slots0.data_ptr()
+        lsp = P["ls"]
+        heads_fwd, chain, bscore, steer_sel = L.ic_heads_fwd, L.ic_gemv_chain, L.ic_branch_score, L.ic_steer_select
+
+        def heads(cur: int, par: int, slots_from: int, b: int) -> None:
+            a = i0 + cur
+            ha.H, ha.mask = CP["H"] + a * CS["H"], CP["mask"] + a * CS["mask"]
+            ha.H_par = ptr_of(par)[0]
+            ha.slots_in, ha.slots_out = slots_ptr(slots_from), CP["slots"] + a * CS["slots"]
+            ha.surprise = CP["surprise_o"] + a * CS["surprise_o"] if afd else None
+            ha.logits = CP["logits"] + a * CS["logits"]
+            ha.stats = lsp + (8 + 4 * b) * 4
+            rc = heads_fwd(ha_ref, st)
+            if rc:
+                check(rc, "ic_heads_fwd")
+
+        last = -1
         traces: List[torch.Tensor] = []
+        if not cfg.train_deterministic_inner_loop and (ver is None or steer is None):
+            raise RuntimeError("the branching reasoning loop needs the planner, critic and energy verifier "
+                               "(reference model.py:376-438)")
         if cfg.train_deterministic_inner_loop:
-            cur = -1
+            cur, u_mean = -1, 0.0
             for k in range(K_inner):
-                u_mean = float(1.0 - F.softmax(last_logits, dim=-1).max()) if k > 0 else 0.0
                 gate.value_bias = 0.0
-                cur = step(cur, k, u_mean, 0)
-                last_logits = m._heads(H_of(cur), mask_of(cur))[0]
+                par = cur
+                cur = step(par, k, u_mean, 0)
+                heads(cur, par, par, 0)
                 traces.append(H_of(cur).clone())
-            return cur, last_logits, traces
+                if k + 1 < K_inner:
+                    u_mean = float(ls[8])  # utils.py:127-130 of this step's logits (host sync)
+            return cur, cur, traces
 
         B_br = cfg.B_br
-        motor = m.io_idxs["motor"]
-        branches = [(m.work.slots.clone(), -1) for _ in range(B_br)]  # (workspace slots, step id of H/mask)
-        scores = [torch.tensor(-1e9, device=dev) for _ in range(B_br)]
-        prev = -1
+        branches = [(-1, -1) for _ in range(B_br)]  # (step whose workspace slots, step whose H / mask)
+        u_mean = 0.0
         for k in range(K_inner):
-            H_prev, on = H_of(prev), mask_of(prev).float()
-            ws_prev = (H_prev * on.unsqueeze(-1)).sum(0) / on.sum().clamp_min(1.0)
-            _p, g = m.plan(ws_prev, H_prev[motor])
-            v = m.critic(ws_prev, g).reshape(1)
+            # planner / critic on the best candidate so far, chosen on the device (model.py:371-386)
+            sa.n_cand = len(branches)
+            for c, (_, hstep) in enumerate(branches):
+                sa.H_cand[c], sa.mask_cand[c] = ptr_of(hstep)
+            sa.scores = lsp if k > 0 else None
+            rc = steer_sel(sa_ref, st) or chain(steer, 6, st)
+            if rc:
+                check(rc, "ic_steer_select/ic_gemv_chain")
+            vals = ls.tolist()  # the one host sync of this outer iteration
             if k > 0:
-                u = (1.0 - F.softmax(last_logits, dim=-1).max()).reshape(1)
-                u_mean, v_hat = torch.cat([u, v]).tolist()  # one host sync for both steering scalars
-            else:
-                u_mean, v_hat = 0.0, float(v.item())
+                top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
+                branches = [branches[i] for i in top]
+                traces.append(H_of(branches[0][1]).clone())
+                u_mean = vals[8 + 4 * (B_br - 1)]
+            v_hat = vals[40]
             gate.value_bias = v_hat
             burst = schedule_burst(u_mean, v_hat, m.R)
             for b in range(B_br):
-                m.work.slots = branches[b][0].clone()
-                par = branches[b][1]
+                sl, par = branches[b]
                 cur = step(par, k, u_mean, burst)
-                H_cur = H_of(cur)
-                logits, _rtd, _ws, motor_state = m._heads(H_cur, mask_of(cur))
-                ver_energy = m.verify(motor_state, F.softmax(logits, dim=-1), aux=m._verify_aux(dev, surp_of(cur)))
-                delta_g = goodness(H_cur) - goodness(H_of(par))
-                scores[b] = 0.6 * delta_g + 0.2 * (-ver_energy) + 0.2 * context_logprob(logits)
-                branches[b] = (m.work.slots, cur)
-                last_logits = logits
-            top = torch.topk(torch.stack(scores), k=min(B_br, 2)).indices.tolist()
-            branches = [branches[i] for i in top]
-            scores = [scores[i] for i in top]
-            traces.append(H_of(branches[0][1]).clone())
-            if should_halt(scores, u_mean, k, K_inner):
+                heads(cur, par, sl, b)
+                ver[0].x0 = CP["H"] + (i0 + cur) * CS["H"] + motor * d * 4
+                ver[2].y = lsp + (48 + b) * 4
+                rc = chain(ver, 3, st) or bscore(lsp + (8 + 4 * b) * 4, lsp + (48 + b) * 4, lsp + b * 4, st)
+                if rc:
+                    check(rc, "ic_gemv_chain/ic_branch_score")
+                branches[b] = (cur, cur)
+                last = cur
+            if should_halt(None, u_mean, k, K_inner):
                 break
-            m.work.slots, prev = branches[0]
-        best = int(torch.stack(scores).argmax().item())
-        m.work.slots, cur = branches[best]
-        return cur, last_logits, traces
+        vals = ls.tolist()
+        top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
+        branches = [branches[i] for i in top]
+        traces.append(H_of(branches[0][1]).clone())
+        return branches[0][1], last, traces
 
     # ------------------------------------------------------------------ backward
     def backward(self, s: _Sample, gH_final: torch.Tensor):

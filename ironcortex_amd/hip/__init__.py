@@ -60,14 +60,18 @@ def parse_header(path: str = HEADER_PATH):
             all_ptr = "*" in decl  # the header never mixes pointers and values in one declaration
             for var in rest.split(","):
                 var = var.replace("*", "").strip()
+                arr = re.match(r"(\w+)\[(\d+)\]$", var)  # fixed-size array member
+                if arr:
+                    var = arr.group(1)
                 if all_ptr:
-                    fields.append((var, ctypes.c_void_p))
+                    ct = ctypes.c_void_p
                 elif base in _SCALARS:
-                    fields.append((var, _SCALARS[base]))
+                    ct = _SCALARS[base]
                 elif base in classes:
-                    fields.append((var, classes[base]))
+                    ct = classes[base]
                 else:
                     raise ValueError(f"cannot parse field '{decl}' in struct {name}")
+                fields.append((var, ct * int(arr.group(2)) if arr else ct))
         structs[name] = fields
         classes[name] = type(name, (ctypes.Structure,), {"_fields_": fields})
     funcs = re.findall(r"^\s*(?:const char\*|int)\s+(ic_\w+)\s*\(", text, flags=re.M)
@@ -95,6 +99,9 @@ def lib():
         for fn in FUNCTIONS:
             if fn not in ("ic_last_error", "ic_prof_kernel_name"):
                 getattr(_lib, fn).restype = ctypes.c_int
+        vp = ctypes.c_void_p  # raw device addresses are passed as Python ints: declare them 64-bit
+        _lib.ic_branch_score.argtypes = [vp, vp, vp, vp]
+        _lib.ic_gemv_chain.argtypes = [vp, ctypes.c_int32, vp]
     return _lib
 
 

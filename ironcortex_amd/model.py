@@ -18,6 +18,7 @@ from .config import CortexConfig
 from .constants import EPS_DIV
 from .energy import EnergyVerifierHead
 from .engine import LoopEngine
+from .flat import FlatParams
 from .gate import Gate, Router
 from .heads import CriticHead, PlannerHead, RTDHead, TokenHead_MFS, Workspace
 from .hip import ops
@@ -81,6 +82,10 @@ class CortexReasoner(nn.Module):
         self.norm_in = RMSNorm(self.d)
         self.reg_ff = nn.ModuleList([RegionFFState() for _ in range(self.R)])
         self.apply(init_weights)
+        # facets / region heads as stacked arenas ([Kf,V,d], [R,V,d]) for the loop-heads kernel
+        object.__setattr__(self, "_heads_flat", FlatParams({
+            "facet_W": [f.weight for f in self.lm_head.facets], "facet_b": [f.bias for f in self.lm_head.facets],
+            "rh_W": [h.weight for h in self.region_heads], "rh_b": [h.bias for h in self.region_heads]}))
         self._profile_times = {"attention": 0.0, "routing": 0.0, "region": 0.0, "total": 0.0}
         self._profile_mem = {"attention": 0, "routing": 0, "region": 0}
         self._sensor_cache = None
@@ -98,6 +103,7 @@ class CortexReasoner(nn.Module):
     def _apply(self, fn, recurse=True):
         super()._apply(fn, recurse)
         self.bank.to_device()
+        self._heads_flat.reflat()
         return self
 
     def count_units(self, on: bool) -> None:
