@@ -351,6 +351,9 @@ int ic_steer_select(const ic_steer_args* a, ic_stream_t stream);
  * HIP events on its own stream; ic_prof_read() synchronises on them and returns the number of
  * launches and their summed duration since the previous read.  Used by bench.py's roofline. */
 int ic_prof_enable(int on);
+/* Bracket only kernel id `kid` (-1 = all): two event records per launch cost more than some of
+ * these kernels run, so a throughput measurement times just the kernel it reports on. */
+int ic_prof_select(int kid);
 int ic_prof_kernel_count(void);
 const char* ic_prof_kernel_name(int kid);
 int ic_prof_read(int kid, int64_t* launches, double* total_ms);

@@ -169,13 +169,15 @@ enum IcKid {
 
 // Optional live kernel timing with HIP events on the launch stream (ic_prof_* in the header).
 extern bool g_ic_prof_on;
+extern int g_ic_prof_only;
 void ic_prof_begin(int kid, hipStream_t st);
 void ic_prof_end(int kid, hipStream_t st);
 #define IC_TIMED(kid, st, ...)                                  \
   do {                                                          \
-    if (g_ic_prof_on) ic_prof_begin(kid, (hipStream_t)(st));    \
+    const bool t__ = g_ic_prof_on && (g_ic_prof_only < 0 || g_ic_prof_only == (kid)); \
+    if (t__) ic_prof_begin(kid, (hipStream_t)(st));             \
     __VA_ARGS__;                                                \
-    if (g_ic_prof_on) ic_prof_end(kid, (hipStream_t)(st));      \
+    if (t__) ic_prof_end(kid, (hipStream_t)(st));               \
   } while (0)
 
 static inline int ic_ceil_div(int a, int b) { return (a + b - 1) / b; }

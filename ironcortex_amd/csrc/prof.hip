@@ -7,6 +7,7 @@
 #include "ic_common.h"
 
 bool g_ic_prof_on = false;
+int g_ic_prof_only = -1;  // -1: every kernel; otherwise only this kernel id is bracketed
 
 namespace {
 struct Pair {
@@ -40,6 +41,11 @@ void ic_prof_end(int kid, hipStream_t st) {
 
 extern "C" int ic_prof_enable(int on) {
   g_ic_prof_on = on != 0;
+  return IC_OK;
+}
+extern "C" int ic_prof_select(int kid) {
+  IC_REQUIRE(kid >= -1 && kid < IC_KID_COUNT, "ic_prof_select: kid=%d", kid);
+  g_ic_prof_only = kid;
   return IC_OK;
 }
 extern "C" int ic_prof_kernel_count(void) { return IC_KID_COUNT; }

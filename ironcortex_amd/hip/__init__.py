@@ -149,6 +149,16 @@ def prof_enable(on: bool) -> None:
     lib().ic_prof_enable(ctypes.c_int(1 if on else 0))
 
 
+def prof_select(name: str = "") -> None:
+    """Time only the named kernel ("" = all)."""
+    l = lib()
+    kid = -1
+    if name:
+        names = [l.ic_prof_kernel_name(ctypes.c_int(k)).decode() for k in range(l.ic_prof_kernel_count())]
+        kid = names.index(name)
+    check(l.ic_prof_select(ctypes.c_int(kid)), "ic_prof_select")
+
+
 def prof_read() -> dict:
     """{kernel name: (launches, total_ms)} since the previous read (synchronises)."""
     out = {}
