@@ -97,7 +97,11 @@ class IronRoPESelfAttention(nn.Module):
             nn.init.normal_(self.beta_sin, std=0.01)
             self.fb_scale = 1.0 / math.sqrt(self.fb_m)
 
-    def forward(self, x, coords=None, update_mask=None, context_mask=None, dropout: bool = True):
+    def forward(self, x, coords=None, update_mask=None, context_mask=None, dropout: bool = True,
+                valid_len: Optional[torch.Tensor] = None):
+        """valid_len [B] (batched sensor vectors only): positions >= valid_len[b] are padding;
+        they are masked out as keys and left out of the per-sample attention energy, so every
+        sample sees exactly what a batch-of-one call on its own rows would see."""
         B, T, C = x.shape
         assert T <= self.block_size
         if coords is None:
@@ -117,10 +121,22 @@ class IronRoPESelfAttention(nn.Module):
         if self.causal:
             keep = torch.ones(T, T, dtype=torch.bool, device=x.device).tril()
             att = att.masked_fill(~keep, float("-inf"))
+        valid = None
+        if valid_len is not None:
+            valid = torch.arange(T, device=x.device).unsqueeze(0) < valid_len.unsqueeze(1)  # [B,T]
+            context_mask = valid if context_mask is None else (context_mask.to(torch.bool) & valid)
         if context_mask is not None:
             att = att.masked_fill(~context_mask[:, None, None, :].to(torch.bool), float("-inf"))
         att = F.softmax(att, dim=-1)
-        self.last_attn_energy = (-(att + EPS_LOG).log().mean()).detach()
+        with torch.no_grad():
+            logp = (att + EPS_LOG).log()
+            if valid is None:
+                self.last_attn_energy_b = -logp.mean(dim=(1, 2, 3))
+            else:
+                both = (valid.unsqueeze(2) & valid.unsqueeze(1)).unsqueeze(1).to(logp.dtype)  # [B,1,T,T]
+                cnt = valid_len.to(logp.dtype).pow(2) * self.n_head
+                self.last_attn_energy_b = -(logp * both).sum(dim=(1, 2, 3)) / cnt
+            self.last_attn_energy = self.last_attn_energy_b.mean() if valid is not None else -logp.mean()
         if dropout:
             att = self.adrop(att)
         y = self.c_proj((att @ v).transpose(1, 2).contiguous().view(B, T, C))
@@ -167,6 +183,9 @@ class AdaptiveFilterAttention(nn.Module):
         logp = (attn + EPS_LOG).log()
         self.last_attn_energy = (-logp.mean()).detach()
         self.last_attn_entropy = (-(logp * attn).sum(dim=-1).mean()).detach()
+        # per-sample values for batched sensor vectors (equal to the scalars when B == 1)
+        self.last_attn_energy_b = (-logp.mean(dim=(1, 2, 3))).detach()
+        self.last_attn_entropy_b = (-(logp * attn).sum(dim=-1).mean(dim=(1, 2))).detach()
         return attn @ v
 
     def forward(self, x, mask=None):
@@ -201,7 +220,7 @@ class LocalTokenMixer(nn.Module):
         self.apply(init_weights)
 
     @torch.no_grad()
-    def build_anchors(self, T: int, focus_mask: torch.Tensor, strides=(128, 32)) -> List[Tuple[int, int]]:
+    def build_anchors(self, T: int, focus_mask, strides=(128, 32)) -> List[Tuple[int, int]]:
         if not self.use_anchors:
             return []
         anchors = [(i, 0) for S in strides for i in range(S // 2, T, S)]
@@ -217,12 +236,15 @@ class LocalTokenMixer(nn.Module):
         if not self.use_anchors:
             pooled = masked_mean(self.attn(tok_emb), focus_mask)
             self.last_energy = self.attn.last_attn_energy.detach()
+            self.last_energy_b = self.attn.last_attn_energy_b
             return pooled
         rows, n_max = [], 0
+        focus_host = focus_mask.tolist() if focus_mask is not None else [None] * B  # one host read
         for b in range(B):
-            anchors = self.build_anchors(T, focus_mask[b])
+            anchors = self.build_anchors(T, focus_host[b])
             rows.append(anchors)
             n_max = max(n_max, len(anchors))
+        ragged = any(len(a) != n_max for a in rows)
         Ta = T + n_max
         X = torch.zeros(B, Ta, d, device=dev)
         C = torch.zeros(B, Ta, 2, device=dev)
@@ -236,7 +258,9 @@ class LocalTokenMixer(nn.Module):
                 X[b, T:T + n] = self.anch_embed[a_kind]
                 pos = a_idx.to(torch.float32)
                 C[b, T:T + n] = torch.stack([pos, pos / (T + EPS_DIV)], dim=-1)
-        Y = self.attn(X, coords=C, update_mask=UM, context_mask=None, dropout=use_dropout)
+        valid_len = torch.tensor([T + len(a) for a in rows], device=dev) if ragged else None
+        Y = self.attn(X, coords=C, update_mask=UM, context_mask=None, dropout=use_dropout, valid_len=valid_len)
         pooled = masked_mean(Y[:, :T, :], focus_mask)
         self.last_energy = self.attn.last_attn_energy.detach()
+        self.last_energy_b = self.attn.last_attn_energy_b
         return pooled

@@ -89,6 +89,7 @@ class CortexReasoner(nn.Module):
         self._profile_times = {"attention": 0.0, "routing": 0.0, "region": 0.0, "total": 0.0}
         self._profile_mem = {"attention": 0, "routing": 0, "region": 0}
         self._sensor_cache = None
+        self._sensor_override = None
         self.counters = {"inner_steps": 0}
         self._units = None  # device counters for bench.py (off by default)
         self._loop_cache = None
@@ -171,6 +172,8 @@ class CortexReasoner(nn.Module):
     def sensor_vector(self, tokens: torch.Tensor, focus_map: torch.Tensor) -> torch.Tensor:
         """model.py:231-247.  The mixer sees only (tokens, focus), never the region state, and
         its dropouts have p = 0, so within one reasoning loop the result is reused."""
+        if self._sensor_override is not None:  # row of a batched mixer call (reasoning_loop_batch)
+            return self._sensor_override
         key = (tokens.data_ptr(), tokens._version, focus_map.data_ptr(), focus_map._version,
                torch.is_grad_enabled(), next(self.local_mix.parameters())._version)
         if self._sensor_cache is not None and self._sensor_cache[0] == key:
@@ -182,6 +185,20 @@ class CortexReasoner(nn.Module):
         vec = self.local_mix(tok_emb, pos, focus_map.unsqueeze(0), ws_slots=None, use_dropout=self.cfg.ff_dropout)[0]
         self._sensor_cache = (key, vec, tokens, focus_map)
         return vec
+
+    def sensor_vectors_batch(self, tokens_batch: torch.Tensor, focus_batch: torch.Tensor):
+        """All sequences of a batch through the token mixer in ONE call.  The
+        mixer sees only (tokens, focus), never the region state, so row b equals
+        sensor_vector(tokens_batch[b], focus_batch[b]); padding anchors are masked out
+        (mixer.py valid_len).  Returns (vectors [N,d], mixer energy [N], attention entropy [N] or None)."""
+        N, T = tokens_batch.shape
+        dev = tokens_batch.device
+        tok_emb = self.embed(tokens_batch)
+        idx = torch.arange(T, device=dev, dtype=torch.float32)
+        pos = torch.stack([idx, idx / (T + EPS_DIV)], dim=-1).unsqueeze(0).expand(N, T, 2)
+        vec = self.local_mix(tok_emb, pos, focus_batch, ws_slots=None, use_dropout=self.cfg.ff_dropout)
+        ent = getattr(self.local_mix.attn, "last_attn_entropy_b", None)
+        return vec, self.local_mix.last_energy_b.detach(), (ent.detach() if ent is not None else None)
 
     # ------------------------------------------------------------------ one inner micro-step
     def forward_inner_step(self, tokens: torch.Tensor, step_k: int, focus_map: torch.Tensor, H_prev: torch.Tensor,
@@ -359,12 +376,24 @@ class CortexReasoner(nn.Module):
         next (detached), exactly as the reference (model.py:462-503)."""
         dev = tokens_batch.device
         H_l, M_l, L_l, T_l, E_l, A_l = [], [], [], [], [], []
-        for b in range(tokens_batch.shape[0]):
-            self.detach_state()
-            H_prev, mask_prev = self.zeros_state(dev)
-            H_cur, reg_mask, logits, traces = self.reasoning_loop(tokens_batch[b], K_inner, focus_batch[b], mask_prev, H_prev)
-            H_l.append(H_cur); M_l.append(reg_mask); L_l.append(logits); T_l.append(traces)
-            E_l.append(self.local_mix.last_energy.detach())
-            ent = getattr(getattr(self.local_mix, "attn", None), "last_attn_entropy", torch.tensor(0.0))
-            A_l.append(ent.detach().to(dev))
+        N = tokens_batch.shape[0]
+        batched = None
+        if N > 1 and tokens_batch.is_cuda and not self.cfg.ff_dropout and not self.cfg.profile:
+            batched = self.sensor_vectors_batch(tokens_batch, focus_batch)  # the loops only differ in region state
+        try:
+            for b in range(N):
+                self.detach_state()
+                H_prev, mask_prev = self.zeros_state(dev)
+                if batched is not None:  # what a per-sequence mixer call would have left behind
+                    self._sensor_override = batched[0][b]
+                    self.local_mix.last_energy = batched[1][b]
+                    if batched[2] is not None:
+                        self.local_mix.attn.last_attn_entropy = batched[2][b]
+                H_cur, reg_mask, logits, traces = self.reasoning_loop(tokens_batch[b], K_inner, focus_batch[b], mask_prev, H_prev)
+                H_l.append(H_cur); M_l.append(reg_mask); L_l.append(logits); T_l.append(traces)
+                E_l.append(self.local_mix.last_energy.detach())
+                ent = getattr(getattr(self.local_mix, "attn", None), "last_attn_entropy", torch.tensor(0.0))
+                A_l.append(ent.detach().to(dev))
+        finally:
+            self._sensor_override = None
         return (torch.stack(H_l), torch.stack(M_l), torch.stack(L_l), T_l, torch.stack(E_l), torch.stack(A_l))

@@ -83,7 +83,7 @@ def masked_mean(Y: torch.Tensor, M: torch.Tensor) -> torch.Tensor:
 
 def extract_spans(mask_1d_bool: torch.Tensor) -> List[Tuple[int, int]]:
     """Half-open [start, end) runs of True (utils.py:71-81)."""
-    bits = mask_1d_bool.tolist()
+    bits = mask_1d_bool.tolist() if hasattr(mask_1d_bool, "tolist") else list(mask_1d_bool)
     spans, start = [], None
     for i, b in enumerate(bits + [False]):
         if b and start is None:
