@@ -328,6 +328,10 @@ typedef struct ic_heads_args {
 } ic_heads_args;
 int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
 
+/* The energy verifier chain (energy.py:12-30; last layer -> scalar energy) followed by the branch
+ * score below, in the same launch when the chain is small. */
+int ic_verify_score(const ic_gemv_desc* descs, int32_t n, const float* stats, float* score,
+                    ic_stream_t stream);
 /* score = 0.6*stats[2] + 0.2*(-energy) + 0.2*stats[1]   (model.py:431-438) */
 int ic_branch_score(const float* stats, const float* energy, float* score, ic_stream_t stream);
 

@@ -35,7 +35,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // One wave per output row, 8 rows per workgroup; the input vector is staged (and optionally
 // layer-normalised) in LDS once per workgroup.
-__global__ __launch_bounds__(256) void k_gemv(ic_gemv_desc g) {
+__global__ __launch_bounds__(256) void k_gemv(ic_gemv_desc g, const float* stats, float* score) {
   __shared__ float xs[kMaxCols];
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,18 +68,119 @@ __global__ __launch_bounds__(256) void k_gemv(ic_gemv_desc g) {
     float acc = 0.f;
     for (int c = lane; c < cols; c += 64) acc = fmaf(w[c], xs[c], acc);
     acc = wave_sum(acc);
-    if (lane == 0) g.y[row] = apply_act(acc + (g.b ? g.b[row] : 0.f), g.act);
+    if (lane == 0) {
+      const float out = apply_act(acc + (g.b ? g.b[row] : 0.f), g.act);
+      g.y[row] = out;
+      // the verifier's last layer: energy -> branch score (model.py:431-438)
+      if (score && row == 0) score[0] = 0.6f * stats[2] + 0.2f * (-out) + 0.2f * stats[1];
+    }
   }
 }
 
-// slots_out[j] = KWTA(slots_in[j] + H[j-th active region], k)     (model.py:300-306, heads.py:34-36)
-template <int DCH>
-__global__ __launch_bounds__(256) void k_ws_write(ic_heads_args a) {
+// A whole chain of small GEMVs in ONE workgroup (16 waves): layer i+1 reads layer i's output
+// after a workgroup barrier, so a 3-6 layer MLP costs one launch instead of one per layer.
+// At <= a few MB of (cache-resident) weights the launch gaps dominate, not the single CU's
+// bandwidth.  Optional epilogue: the branch score of model.py:431-438 from the last output.
+struct ChainArgs {
+  ic_gemv_desc d[6];
+  int n;
+  const float* stats;
+  float* score;
+};
+
+__device__ __forceinline__ float block_sum16(float v, float* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += red[i];
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void k_gemv_chain1(ChainArgs c) {
+  __shared__ __align__(16) float xs[kMaxCols];
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RPI = 8;  // rows in flight per wave
+  for (int L = 0; L < c.n; ++L) {
+    const ic_gemv_desc& g = c.d[L];
+    const int cols = g.n0 + g.n1 + g.n2;
+    for (int i = threadIdx.x; i < cols; i += 1024) {
+      float v;
+      if (i < g.n0) v = g.x0[i];
+      else if (i < g.n0 + g.n1) v = g.x1[i - g.n0];
+      else v = g.x2[i - g.n0 - g.n1];
+      xs[i] = v;
+    }
+    __syncthreads();
+    if (g.ln_g) {
+      float s = 0.f;
+      for (int i = threadIdx.x; i < cols; i += 1024) s += xs[i];
+      const float mean = block_sum16(s, red) / (float)cols;
+      float q = 0.f;
+      for (int i = threadIdx.x; i < cols; i += 1024) {
+        const float t = xs[i] - mean;
+        q += t * t;
+      }
+      const float rstd = 1.0f / sqrtf(block_sum16(q, red) / (float)cols + g.ln_eps);
+      for (int i = threadIdx.x; i < cols; i += 1024) xs[i] = (xs[i] - mean) * rstd * g.ln_g[i] + g.ln_b[i];
+      __syncthreads();
+    }
+    const bool vec4 = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.W) & 15) == 0);
+    for (int r0 = wave * RPI; r0 < g.rows; r0 += 16 * RPI) {
+      float acc[RPI];
+#pragma unroll
+      for (int i = 0; i < RPI; ++i) acc[i] = 0.f;
+      if (vec4) {
+        for (int c4 = lane; c4 < cols / 4; c4 += 64) {
+          const float4 xv = *reinterpret_cast<const float4*>(xs + 4 * c4);
+#pragma unroll
+          for (int i = 0; i < RPI; ++i) {
+            if (r0 + i < g.rows) {
+              const float4 w = *reinterpret_cast<const float4*>(g.W + (size_t)(r0 + i) * cols + 4 * c4);
+              acc[i] = fmaf(w.x, xv.x, acc[i]);
+              acc[i] = fmaf(w.y, xv.y, acc[i]);
+              acc[i] = fmaf(w.z, xv.z, acc[i]);
+              acc[i] = fmaf(w.w, xv.w, acc[i]);
+            }
+          }
+        }
+      } else {
+        for (int cc = lane; cc < cols; cc += 64) {
+          const float xv = xs[cc];
+#pragma unroll
+          for (int i = 0; i < RPI; ++i)
+            if (r0 + i < g.rows) acc[i] = fmaf(g.W[(size_t)(r0 + i) * cols + cc], xv, acc[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RPI; ++i) {
+        const float t = wave_sum(acc[i]);
+        if (lane == 0 && r0 + i < g.rows) g.y[r0 + i] = apply_act(t + (g.b ? g.b[r0 + i] : 0.f), g.act);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (c.score && threadIdx.x == 0) {
+    const float energy = c.d[c.n - 1].y[0];
+    c.score[0] = 0.6f * c.stats[2] + 0.2f * (-energy) + 0.2f * c.stats[1];
+  }
+}
+
+// ONE launch for the heads of an inner step.  blockIdx.y selects the work:
+//   0            z = [gate; facets] . H[motor] + bias                    (heads.py:96-119)
+//   1 + r        region head r on H[r], active regions other than motor  (model.py:311-318)
+//   1 + R        slots_out[j] = KWTA(slots_in[j] + H[j-th active region]) (model.py:300-306, heads.py:34-36)
+// and the last workgroup to finish combines: logits, softmax, steering statistics.
+template <int DCH>
+__device__ __forceinline__ void ws_write_rows(const ic_heads_args& a, int lane, int wave) {
   const int j = blockIdx.x * 4 + wave;
   if (j >= a.n_slots) return;
-  // index of the (j+1)-th set bit of mask
-  int found = -1, seen = 0;
+  int found = -1, seen = 0;  // index of the (j+1)-th set bit of mask
   for (int base = 0; base < a.R && found < 0; base += 64) {
     const int r = base + lane;
     const bool on = r < a.R && a.mask[r] != 0;
@@ -106,11 +207,8 @@ __global__ __launch_bounds__(256) void k_ws_write(ic_heads_args a) {
   store_row(out, a.slots_out + (size_t)j * d, d, lane);
 }
 
-// blockIdx.y == 0: z = lm_W . H[motor] + lm_b (gate + facets); blockIdx.y == 1 + r: the head of
-// active region r != motor on H[r].  One wave per two rows.
 template <int DCH>
-__global__ __launch_bounds__(256) void k_token_rows(ic_heads_args a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void token_rows(const ic_heads_args& a, int lane, int wave) {
   const int d = a.d;
   const int grp = blockIdx.y;
   int rows;
@@ -155,63 +253,100 @@ __global__ __launch_bounds__(256) void k_token_rows(ic_heads_args a) {
   }
 }
 
-// One workgroup: mixture-of-facets logits + region heads -> logits, softmax, steering statistics.
-__global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a) {
-  __shared__ float red[4];
-  const int V = a.V, Kf = a.Kf;
-  // facet gate: softmax over Kf (every thread, Kf is tiny)
-  float gmx = -INFINITY;
-  for (int f = 0; f < Kf; ++f) gmx = fmaxf(gmx, a.z[f]);
-  float gsum = 0.f;
-  for (int f = 0; f < Kf; ++f) gsum += expf(a.z[f] - gmx);
+// mixture-of-facets logits + region heads -> logits, softmax, steering statistics (one workgroup)
+__device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* red) {
+  constexpr int VPT = 4;  // V <= 1024 (checked on the host)
+  const int V = a.V, Kf = a.Kf, R = a.R, tid = threadIdx.x;
+  // issue every independent global read first: one round trip instead of a chain of them
+  constexpr int KF = 16;  // Kf <= 16 (checked on the host); fixed trip counts keep zg in registers
+  float zg[KF];
+#pragma unroll
+  for (int f = 0; f < KF; ++f) zg[f] = f < Kf ? a.z[f] : -INFINITY;
   float nw = 0.f;
-  for (int r = 0; r < a.R; ++r) nw += (r != a.motor_idx && a.mask[r]) ? 1.0f : 0.0f;
-  const float denom = 1.0f + nw;
-  float mx = -INFINITY;
-  for (int v = threadIdx.x; v < V; v += 256) {
-    float acc = 0.f;
-    for (int f = 0; f < Kf; ++f) acc += (expf(a.z[f] - gmx) / gsum) * a.z[Kf + f * V + v];
-    float reg = 0.f;
-    for (int r = 0; r < a.R; ++r)
-      if (r != a.motor_idx && a.mask[r]) reg += a.per_region[(size_t)r * V + v];
-    const float lg = (acc + reg) / denom;
-    a.logits[v] = lg;
-    mx = fmaxf(mx, lg);
-  }
-  mx = block_max(mx, red);
-  float se = 0.f;
-  for (int v = threadIdx.x; v < V; v += 256) se += expf(a.logits[v] - mx);
-  se = block_sum(se, red);
-  float clp = 0.f, pmax = 0.f;
-  for (int v = threadIdx.x; v < V; v += 256) {
-    const float p = expf(a.logits[v] - mx) / se;
-    a.probs[v] = p;
-    clp += p * logf(p + 1e-12f);
-    pmax = fmaxf(pmax, p);
-  }
-  clp = block_sum(clp, red);
-  pmax = block_max(pmax, red);
-  // goodness(H) - goodness(H_par): mean over regions of mean_d h^2   (utils.py:159-162)
-  const int n = a.R * a.d;
-  float g1 = 0.f, g0 = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int r = 0; r < R; ++r) nw += (r != a.motor_idx && a.mask[r]) ? 1.0f : 0.0f;
+  const int n = R * a.d;
+  float g1 = 0.f, g0 = 0.f, sp = 0.f;
+  for (int i = tid; i < n; i += 256) {  // goodness(H) - goodness(H_par)   (utils.py:159-162)
     const float h1 = a.H[i], h0 = a.H_par[i];
     g1 = fmaf(h1, h1, g1);
     g0 = fmaf(h0, h0, g0);
   }
+  if (a.surprise)
+    for (int r = tid; r < R; r += 256) sp += a.surprise[r];
+  float gmx = -INFINITY;
+#pragma unroll
+  for (int f = 0; f < KF; ++f) gmx = fmaxf(gmx, zg[f]);
+  float gsum = 0.f;
+#pragma unroll
+  for (int f = 0; f < KF; ++f) {
+    zg[f] = f < Kf ? expf(zg[f] - gmx) : 0.f;
+    gsum += zg[f];
+  }
+  const float denom = 1.0f + nw;
+  float lg[VPT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int v = tid + 256 * j;
+    lg[j] = -INFINITY;
+    if (v < V) {
+      float acc = 0.f;
+#pragma unroll
+      for (int f = 0; f < KF; ++f)
+        if (f < Kf) acc += (zg[f] / gsum) * a.z[Kf + f * V + v];
+      float reg = 0.f;
+      for (int r = 0; r < R; ++r)
+        if (r != a.motor_idx && a.mask[r]) reg += a.per_region[(size_t)r * V + v];
+      lg[j] = (acc + reg) / denom;
+      a.logits[v] = lg[j];
+      mx = fmaxf(mx, lg[j]);
+    }
+  }
+  mx = block_max(mx, red);
+  float se = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j)
+    if (tid + 256 * j < V) se += expf(lg[j] - mx);
+  se = block_sum(se, red);
+  float clp = 0.f, pmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int v = tid + 256 * j;
+    if (v < V) {
+      const float p = expf(lg[j] - mx) / se;
+      a.probs[v] = p;
+      clp += p * logf(p + 1e-12f);
+      pmax = fmaxf(pmax, p);
+    }
+  }
+  clp = block_sum(clp, red);
+  pmax = block_max(pmax, red);
   g1 = block_sum(g1, red);
   g0 = block_sum(g0, red);
-  float sp = 0.f;
-  if (a.surprise)
-    for (int r = threadIdx.x; r < a.R; r += 256) sp += a.surprise[r];
-  sp = block_sum(sp, red) / (float)a.R;
-  if (threadIdx.x == 0) {
+  sp = block_sum(sp, red) / (float)R;
+  if (tid == 0) {
     a.stats[0] = 1.0f - pmax;
     a.stats[1] = clp;
     a.stats[2] = g1 / (float)n - g0 / (float)n;
     a.stats[3] = sp;
     if (a.aux_surprise) *a.aux_surprise = sp;
   }
+}
+
+// Measured on MI355X: electing a last workgroup to run the combine in the same launch
+// (device-scope fence + ticket per workgroup) cost 190 us for this 3000-workgroup grid -- the
+// fences write back / invalidate the per-XCD L2s -- against ~6 us for a second launch.  So the
+// combine stays a launch of its own.
+template <int DCH>
+__global__ __launch_bounds__(256) void k_heads(ic_heads_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.y == a.R + 1) ws_write_rows<DCH>(a, lane, wave);
+  else token_rows<DCH>(a, lane, wave);
+}
+
+__global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a) {
+  __shared__ float red[4];
+  logits_combine(a, red);
 }
 
 __global__ void k_branch_score(const float* stats, const float* energy, float* score) {
@@ -249,28 +384,65 @@ __global__ __launch_bounds__(256) void k_steer_select(ic_steer_args a) {
 
 }  // namespace
 
+static int check_gemv(const ic_gemv_desc& g, int i, const char* who) {
+  const int cols = g.n0 + g.n1 + g.n2;
+  IC_REQUIRE(g.W && g.y && g.rows > 0, "%s[%d]: NULL W/y or rows=%d", who, i, g.rows);
+  IC_REQUIRE(g.n0 >= 0 && g.n1 >= 0 && g.n2 >= 0 && cols > 0 && cols <= kMaxCols,
+             "%s[%d]: %d input columns (need 1..%d)", who, i, cols, kMaxCols);
+  IC_REQUIRE((g.n0 == 0 || g.x0) && (g.n1 == 0 || g.x1) && (g.n2 == 0 || g.x2), "%s[%d]: NULL input segment", who, i);
+  IC_REQUIRE(!g.ln_g || g.ln_b, "%s[%d]: LayerNorm weight without bias", who, i);
+  IC_REQUIRE(g.act >= IC_ACT_NONE && g.act <= IC_ACT_SILU, "%s[%d]: act=%d", who, i, g.act);
+  return IC_OK;
+}
+
+// Chains of up to 6 layers and <= 128 KB of weights run as one single-workgroup launch (one CU
+// streams ~25 GB/s: measured 79 us for 2 MB); anything larger goes layer by layer over the chip,
+// the last layer folding in the branch score.
+static int run_chain(const ic_gemv_desc* descs, int n, const float* stats, float* score, hipStream_t st,
+                     const char* who) {
+  size_t bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    int rc = check_gemv(descs[i], i, who);
+    if (rc) return rc;
+    bytes += (size_t)descs[i].rows * (descs[i].n0 + descs[i].n1 + descs[i].n2) * 4;
+  }
+  if (n >= 1 && n <= 6 && bytes <= (128u << 10)) {
+    ChainArgs c;
+    for (int i = 0; i < n; ++i) c.d[i] = descs[i];
+    c.n = n;
+    c.stats = stats;
+    c.score = score;
+    IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_chain1, dim3(1), dim3(1024), 0, st, c));
+    return IC_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    float* sc = (i == n - 1) ? score : nullptr;
+    IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv, dim3(ic_ceil_div(descs[i].rows, 8)), dim3(256), 0, st, descs[i], stats, sc));
+  }
+  return IC_OK;
+}
+
 extern "C" int ic_gemv_chain(const ic_gemv_desc* descs, int32_t n, ic_stream_t stream) {
   IC_REQUIRE(descs != nullptr && n >= 0, "ic_gemv_chain: NULL descriptors");
-  hipStream_t st = (hipStream_t)stream;
-  for (int i = 0; i < n; ++i) {
-    const ic_gemv_desc& g = descs[i];
-    const int cols = g.n0 + g.n1 + g.n2;
-    IC_REQUIRE(g.W && g.y && g.rows > 0, "ic_gemv_chain[%d]: NULL W/y or rows=%d", i, g.rows);
-    IC_REQUIRE(g.n0 >= 0 && g.n1 >= 0 && g.n2 >= 0 && cols > 0 && cols <= kMaxCols,
-               "ic_gemv_chain[%d]: %d input columns (need 1..%d)", i, cols, kMaxCols);
-    IC_REQUIRE((g.n0 == 0 || g.x0) && (g.n1 == 0 || g.x1) && (g.n2 == 0 || g.x2),
-               "ic_gemv_chain[%d]: NULL input segment", i);
-    IC_REQUIRE(!g.ln_g || g.ln_b, "ic_gemv_chain[%d]: LayerNorm weight without bias", i);
-    IC_REQUIRE(g.act >= IC_ACT_NONE && g.act <= IC_ACT_SILU, "ic_gemv_chain[%d]: act=%d", i, g.act);
-    IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv, dim3(ic_ceil_div(g.rows, 8)), dim3(256), 0, st, g));
-  }
+  int rc = run_chain(descs, n, nullptr, nullptr, (hipStream_t)stream, "ic_gemv_chain");
+  if (rc) return rc;
   IC_LAUNCH_CHECK("ic_gemv_chain");
+  return IC_OK;
+}
+
+extern "C" int ic_verify_score(const ic_gemv_desc* descs, int32_t n, const float* stats, float* score,
+                               ic_stream_t stream) {
+  IC_REQUIRE(descs != nullptr && n >= 1 && stats && score, "ic_verify_score: NULL argument");
+  IC_REQUIRE(descs[n - 1].rows == 1, "ic_verify_score: the last layer must produce the scalar energy");
+  int rc = run_chain(descs, n, stats, score, (hipStream_t)stream, "ic_verify_score");
+  if (rc) return rc;
+  IC_LAUNCH_CHECK("ic_verify_score");
   return IC_OK;
 }
 
 extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
   IC_REQUIRE(a != nullptr, "ic_heads_fwd: NULL args");
-  IC_REQUIRE(a->R > 0 && a->V > 0 && a->Kf > 0 && a->Kf <= 64 && a->n_slots >= 0,
+  IC_REQUIRE(a->R > 0 && a->V > 0 && a->Kf > 0 && a->Kf <= 16 && a->n_slots >= 0,
              "ic_heads_fwd: R=%d V=%d Kf=%d n_slots=%d", a->R, a->V, a->Kf, a->n_slots);
   IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "ic_heads_fwd: d=%d unsupported", a->d);
   IC_REQUIRE(a->motor_idx >= 0 && a->motor_idx < a->R, "ic_heads_fwd: motor_idx=%d", a->motor_idx);
@@ -279,12 +451,13 @@ extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
              "ic_heads_fwd: NULL pointer");
   IC_REQUIRE(a->n_slots == 0 || (a->slots_in && a->slots_out), "ic_heads_fwd: NULL workspace slots");
   hipStream_t st = (hipStream_t)stream;
+  IC_REQUIRE(a->V <= 1024, "ic_heads_fwd: V=%d (need <= 1024)", a->V);
   const int lm_rows = a->Kf + a->Kf * a->V;
   const int max_rows = lm_rows > a->V ? lm_rows : a->V;
+  int nx = ic_ceil_div(max_rows, 8);
+  if (ic_ceil_div(a->n_slots, 4) > nx) nx = ic_ceil_div(a->n_slots, 4);
   IC_DISPATCH_DCH(a->d, {
-    if (a->n_slots > 0)
-      IC_TIMED(IC_KID_ws_write, st, hipLaunchKernelGGL(k_ws_write<DCH>, dim3(ic_ceil_div(a->n_slots, 4)), dim3(256), 0, st, *a));
-    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_token_rows<DCH>, dim3(ic_ceil_div(max_rows, 8), 1 + a->R), dim3(256), 0, st, *a));
+    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 2 + a->R), dim3(256), 0, st, *a));
   });
   IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(1), dim3(256), 0, st, *a));
   IC_LAUNCH_CHECK("ic_heads_fwd");

@@ -409,7 +409,7 @@ class LoopEngine:
         slots0 = m.work.slots.detach().contiguous()
         slots_ptr = lambda i: CP["slots"] + (i0 + i) * CS["slots"] if i >= 0 else slots0.data_ptr()
         lsp = P["ls"]
-        heads_fwd, chain, bscore, steer_sel = L.ic_heads_fwd, L.ic_gemv_chain, L.ic_branch_score, L.ic_steer_select
+        heads_fwd, chain, vscore, steer_sel = L.ic_heads_fwd, L.ic_gemv_chain, L.ic_verify_score, L.ic_steer_select
 
         def heads(cur: int, par: int, slots_from: int, b: int) -> None:
             a = i0 + cur
@@ -467,9 +467,9 @@ class LoopEngine:
                 heads(cur, par, sl, b)
                 ver[0].x0 = CP["H"] + (i0 + cur) * CS["H"] + motor * d * 4
                 ver[2].y = lsp + (48 + b) * 4
-                rc = chain(ver, 3, st) or bscore(lsp + (8 + 4 * b) * 4, lsp + (48 + b) * 4, lsp + b * 4, st)
+                rc = vscore(ver, 3, lsp + (8 + 4 * b) * 4, lsp + b * 4, st)
                 if rc:
-                    check(rc, "ic_gemv_chain/ic_branch_score")
+                    check(rc, "ic_verify_score")
                 branches[b] = (cur, cur)
                 last = cur
             if should_halt(None, u_mean, k, K_inner):
