@@ -128,52 +128,86 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
       rs[p] = sinf(th);
     }
   }
-  for (int s = 0; s < a.S; ++s) {
-    const int row = s * a.R + r;
-    if (!a.mask[row]) continue;
+  // Streams are walked 64 at a time from one ballot of the mask; the operands of the NEXT active
+  // stream (x row, dt, and the state scalars lanes 0/1 update) are requested before the current
+  // stream's dot products are reduced, so a stream costs one memory round trip, not three.
+  struct Ops {
     RowFrag<DCH> xv;
-    load_row(xv, a.x + (size_t)row * d, d, lane);
-    const float steps = (float)(a.dt[row] + 1);
+    float steps;
+    float num[PP], den[PP], var[PP];
+  };
+  auto request = [&](int s, Ops& o) {
+    const int row = s * a.R + r;
+    load_row(o.xv, a.x + (size_t)row * d, d, lane);
+    o.steps = (float)(a.dt[row] + 1);
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
-      const float pr0 = wave_sum(dot_frag(wr[2 * p], xv)), pr1 = wave_sum(dot_frag(wr[2 * p + 1], xv));
-      const float pk0 = wave_sum(dot_frag(wk[2 * p], xv)), pk1 = wave_sum(dot_frag(wk[2 * p + 1], xv));
-      const float pv0 = wave_sum(dot_frag(wv[2 * p], xv)), pv1 = wave_sum(dot_frag(wv[2 * p + 1], xv));
+      o.num[p] = o.den[p] = o.var[p] = 0.f;
       if (lane < 2 && ok[p]) {
         const size_t idx = (size_t)row * d + row0 + 2 * p + lane;
-        const float rr = ic_sigmoid(lane ? pr1 : pr0);
-        const float kk = lane ? pk1 : pk0;
-        float vv = lane ? pv1 : pv0;
-        if (rot[p]) vv = lane ? (pv0 * rs[p] + pv1 * rc[p]) : (pv0 * rc[p] - pv1 * rs[p]);  // iron_rope.py:63-64
-        const float lam = fmaxf(expf(rate[p] * steps), IC_EPS_DIV);  // region.py:97-98
-        const float numd = a.num[idx] * lam, dend = a.den[idx] * lam;  // region.py:131-133
-        const float w = expf(fminf(kk, IC_MAX_EXP));  // region.py:190
-        float yv, num_n, den_n;
-        if (afd) {  // region.py:192-212
-          const float vard = a.var[idx] * (lam * lam) + pn[p] * steps;  // region.py:135
-          const float prd = numd / (dend + IC_EPS_DIV);
-          const float resid = w * vv - prd;
-          const float obs = expf(fminf(-kk, IC_MAX_EXP)) * on[p] + IC_EPS_DIV;
-          float gain = vard / (vard + obs);
-          gain = fminf(fmaxf(gain, IC_EPS_DIV), 1.0f);  // fp32(1 - 1e-8) == 1
-          const float st = prd + gain * resid;
-          den_n = dend + w;
-          num_n = st * den_n;
-          a.var_o[idx] = (1.0f - gain) * vard;
-          a.sterm[idx] = (resid * resid) * (1.0f / (vard + obs));
-          yv = rr * st;
-        } else {  // region.py:214-216
-          num_n = numd + w * vv;
-          den_n = dend + w;
-          yv = rr * (num_n / (den_n + IC_EPS_DIV));
-        }
-        a.num_o[idx] = num_n;
-        a.den_o[idx] = den_n;
-        a.y[idx] = yv;
-        a.r_s[idx] = rr;
-        a.k_s[idx] = kk;
-        a.v_s[idx] = vv;
+        o.num[p] = a.num[idx];
+        o.den[p] = a.den[idx];
+        if (afd) o.var[p] = a.var[idx];
       }
+    }
+  };
+  for (int sc = 0; sc < a.S; sc += 64) {
+    const int sl = sc + lane;
+    unsigned long long act = __ballot(sl < a.S && a.mask[sl * a.R + r] != 0);
+    if (!act) continue;
+    Ops cur, nxt;
+    int s_cur = sc + __ffsll((long long)act) - 1;
+    act &= act - 1;
+    request(s_cur, cur);
+    while (s_cur >= 0) {
+      const int s_nxt = act ? sc + __ffsll((long long)act) - 1 : -1;
+      act &= act - 1;
+      if (s_nxt >= 0) request(s_nxt, nxt);
+      const int row = s_cur * a.R + r;
+      const float steps = cur.steps;
+#pragma unroll
+      for (int p = 0; p < PP; ++p) {
+        const float pr0 = wave_sum(dot_frag(wr[2 * p], cur.xv)), pr1 = wave_sum(dot_frag(wr[2 * p + 1], cur.xv));
+        const float pk0 = wave_sum(dot_frag(wk[2 * p], cur.xv)), pk1 = wave_sum(dot_frag(wk[2 * p + 1], cur.xv));
+        const float pv0 = wave_sum(dot_frag(wv[2 * p], cur.xv)), pv1 = wave_sum(dot_frag(wv[2 * p + 1], cur.xv));
+        if (lane < 2 && ok[p]) {
+          const size_t idx = (size_t)row * d + row0 + 2 * p + lane;
+          const float rr = ic_sigmoid(lane ? pr1 : pr0);
+          const float kk = lane ? pk1 : pk0;
+          float vv = lane ? pv1 : pv0;
+          if (rot[p]) vv = lane ? (pv0 * rs[p] + pv1 * rc[p]) : (pv0 * rc[p] - pv1 * rs[p]);  // iron_rope.py:63-64
+          const float lam = fmaxf(expf(rate[p] * steps), IC_EPS_DIV);  // region.py:97-98
+          const float numd = cur.num[p] * lam, dend = cur.den[p] * lam;  // region.py:131-133
+          const float w = expf(fminf(kk, IC_MAX_EXP));  // region.py:190
+          float yv, num_n, den_n;
+          if (afd) {  // region.py:192-212
+            const float vard = cur.var[p] * (lam * lam) + pn[p] * steps;  // region.py:135
+            const float prd = numd / (dend + IC_EPS_DIV);
+            const float resid = w * vv - prd;
+            const float obs = expf(fminf(-kk, IC_MAX_EXP)) * on[p] + IC_EPS_DIV;
+            float gain = vard / (vard + obs);
+            gain = fminf(fmaxf(gain, IC_EPS_DIV), 1.0f);  // fp32(1 - 1e-8) == 1
+            const float st = prd + gain * resid;
+            den_n = dend + w;
+            num_n = st * den_n;
+            a.var_o[idx] = (1.0f - gain) * vard;
+            a.sterm[idx] = (resid * resid) * (1.0f / (vard + obs));
+            yv = rr * st;
+          } else {  // region.py:214-216
+            num_n = numd + w * vv;
+            den_n = dend + w;
+            yv = rr * (num_n / (den_n + IC_EPS_DIV));
+          }
+          a.num_o[idx] = num_n;
+          a.den_o[idx] = den_n;
+          a.y[idx] = yv;
+          a.r_s[idx] = rr;
+          a.k_s[idx] = kk;
+          a.v_s[idx] = vv;
+        }
+      }
+      cur = nxt;
+      s_cur = s_nxt;
     }
   }
 }
@@ -196,44 +230,75 @@ __global__ __launch_bounds__(256) void k_region_out(ic_region_args a) {
     else zero_frag(wo[i]);
   }
   const bool rt = a.flags & IC_F_RT;
-  for (int s = 0; s < a.S; ++s) {
-    const int row = s * a.R + r;
-    if (!a.mask[row]) continue;
+  const float rpn = rt ? ic_noise(a.rpn_param[r]) : 0.f, ron = rt ? ic_noise(a.ron_param[r]) : 0.f;
+  struct Ops {
     RowFrag<DCH> yv;
-    load_row(yv, a.y + (size_t)row * d, d, lane);
-    float scale = 1.0f;
-    if (rt) {  // region.py:219-235
-      const float nrm = fmaxf(sqrtf(wave_sum(dot_frag(yv, yv))), IC_EPS_DIV);
-#pragma unroll
-      for (int j = 0; j < DCH; ++j) {
-        yv.v[j].x /= nrm; yv.v[j].y /= nrm; yv.v[j].z /= nrm; yv.v[j].w /= nrm;
-      }
-      const float rad = a.radius[row];
-      const float pvar = a.radius_var[row] + ic_noise(a.rpn_param[r]);
-      const float resid = nrm - rad;
-      const float gain = pvar / (pvar + ic_noise(a.ron_param[r]) + IC_EPS_DIV);
-      const float upd = rad + gain * resid;
-      const float mu = (float)0.2, omu = (float)(1.0 - 0.2);
-      scale = omu * rad + mu * upd;
-      if (blockIdx.x == 0 && wave == 0) {
-        if (a.last_dir) store_row(yv, a.last_dir + (size_t)row * d, d, lane);
-        if (lane == 0) {
-          a.radius_o[row] = scale;
-          a.radius_var_o[row] = (1.0f - gain) * pvar;
-          a.ynorm[row] = nrm;
-          if (a.last_norm) a.last_norm[row] = nrm;
-        }
-      }
+    float xres[PP];
+    float rad, rvar;
+  };
+  auto request = [&](int s, Ops& o) {
+    const int row = s * a.R + r;
+    load_row(o.yv, a.y + (size_t)row * d, d, lane);
+    o.rad = o.rvar = 0.f;
+    if (rt) {
+      o.rad = a.radius[row];
+      o.rvar = a.radius_var[row];
     }
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
-      const float h0 = wave_sum(dot_frag(wo[2 * p], yv)), h1 = wave_sum(dot_frag(wo[2 * p + 1], yv));
       const int ch = row0 + 2 * p + lane;
-      if (lane < 2 && ch < d) {
-        const size_t idx = (size_t)row * d + ch;
-        const float hd = lane ? h1 : h0;
-        a.hpre[idx] = a.x[idx] + (rt ? scale * hd : hd);
+      o.xres[p] = (lane < 2 && ch < d) ? a.x[(size_t)row * d + ch] : 0.f;
+    }
+  };
+  for (int sc = 0; sc < a.S; sc += 64) {
+    const int sl = sc + lane;
+    unsigned long long act = __ballot(sl < a.S && a.mask[sl * a.R + r] != 0);
+    if (!act) continue;
+    Ops cur, nxt;
+    int s_cur = sc + __ffsll((long long)act) - 1;
+    act &= act - 1;
+    request(s_cur, cur);
+    while (s_cur >= 0) {
+      const int s_nxt = act ? sc + __ffsll((long long)act) - 1 : -1;
+      act &= act - 1;
+      if (s_nxt >= 0) request(s_nxt, nxt);
+      const int row = s_cur * a.R + r;
+      RowFrag<DCH>& yv = cur.yv;
+      float scale = 1.0f;
+      if (rt) {  // region.py:219-235
+        const float nrm = fmaxf(sqrtf(wave_sum(dot_frag(yv, yv))), IC_EPS_DIV);
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          yv.v[j].x /= nrm; yv.v[j].y /= nrm; yv.v[j].z /= nrm; yv.v[j].w /= nrm;
+        }
+        const float rad = cur.rad;
+        const float pvar = cur.rvar + rpn;
+        const float resid = nrm - rad;
+        const float gain = pvar / (pvar + ron + IC_EPS_DIV);
+        const float upd = rad + gain * resid;
+        const float mu = (float)0.2, omu = (float)(1.0 - 0.2);
+        scale = omu * rad + mu * upd;
+        if (blockIdx.x == 0 && wave == 0) {
+          if (a.last_dir) store_row(yv, a.last_dir + (size_t)row * d, d, lane);
+          if (lane == 0) {
+            a.radius_o[row] = scale;
+            a.radius_var_o[row] = (1.0f - gain) * pvar;
+            a.ynorm[row] = nrm;
+            if (a.last_norm) a.last_norm[row] = nrm;
+          }
+        }
       }
+#pragma unroll
+      for (int p = 0; p < PP; ++p) {
+        const float h0 = wave_sum(dot_frag(wo[2 * p], yv)), h1 = wave_sum(dot_frag(wo[2 * p + 1], yv));
+        const int ch = row0 + 2 * p + lane;
+        if (lane < 2 && ch < d) {
+          const float hd = lane ? h1 : h0;
+          a.hpre[(size_t)row * d + ch] = cur.xres[p] + (rt ? scale * hd : hd);
+        }
+      }
+      cur = nxt;
+      s_cur = s_nxt;
     }
   }
 }

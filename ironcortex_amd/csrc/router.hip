@@ -12,7 +12,14 @@ namespace {
 constexpr int kRowsPerBlock = 8;
 
 // ---------------------------------------------------------------- default forward
-template <int DCH>
+// Workgroup = (8-row slice, destination r); incoming edges are walked in index order (the
+// reference's index_add_ order).  Streams are served SB at a time: an edge's two weight rows are
+// loaded once per batch of SB streams (not once per stream) and the batch's sender rows are all
+// requested before the first dot product is reduced.  Low register use on purpose: most
+// workgroups of a launch find no active edge and must come and go quickly.
+// (Tried and measured slower on MI355X at R=512: all <= 8 edges' rows in registers at once,
+// 64-113 us against 28 us -- the idle workgroups pay for the low occupancy.)
+template <int DCH, int SB>
 __global__ __launch_bounds__(256) void k_router_fwd(ic_router_args a) {
   const int r = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -21,22 +28,37 @@ __global__ __launch_bounds__(256) void k_router_fwd(ic_router_args a) {
   if (row0 >= d) return;
   const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
   const size_t dd = (size_t)d * d;
-  for (int s = 0; s < a.S; ++s) {
-    float acc0 = 0.f, acc1 = 0.f;
+  for (int s0 = 0; s0 < a.S; s0 += SB) {
+    float acc0[SB], acc1[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) acc0[i] = acc1[i] = 0.f;
     for (int e = e0; e < e1; ++e) {
       const int src = a.src[e];
-      if (!a.mask_prev[s * a.R + src]) continue;
+      unsigned m = 0;
+#pragma unroll
+      for (int i = 0; i < SB; ++i)
+        if (s0 + i < a.S && a.mask_prev[(s0 + i) * a.R + src]) m |= 1u << i;
+      if (!m) continue;
       const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
-      RowFrag<DCH> w0, w1, h;
+      RowFrag<DCH> w0, w1, h[SB];
       load_row(w0, W, d, lane);
       load_row(w1, W + d, d, lane);
-      load_row(h, a.H + ((size_t)s * a.R + src) * d, d, lane);
-      const float m0 = wave_sum(dot_frag(w0, h)), m1 = wave_sum(dot_frag(w1, h));
       const float bias = a.ebias[e];
-      acc0 += m0 * bias;  // gate.py:290,324 (w == 1)
-      acc1 += m1 * bias;
+#pragma unroll
+      for (int i = 0; i < SB; ++i)
+        if ((m >> i) & 1u) load_row(h[i], a.H + ((size_t)(s0 + i) * a.R + src) * d, d, lane);
+#pragma unroll
+      for (int i = 0; i < SB; ++i) {
+        if ((m >> i) & 1u) {
+          const float m0 = wave_sum(dot_frag(w0, h[i])), m1 = wave_sum(dot_frag(w1, h[i]));
+          acc0[i] += m0 * bias;  // gate.py:290,324 (w == 1)
+          acc1[i] += m1 * bias;
+        }
+      }
     }
-    if (lane < 2) a.M[((size_t)s * a.R + r) * d + row0 + lane] = lane ? acc1 : acc0;
+#pragma unroll
+    for (int i = 0; i < SB; ++i)
+      if (lane < 2 && s0 + i < a.S) a.M[((size_t)(s0 + i) * a.R + r) * d + row0 + lane] = lane ? acc1[i] : acc0[i];
   }
 }
 
@@ -514,7 +536,11 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
       IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<DCH>, dim3(ic_ceil_div(a->S * a->R, 4)), dim3(256), 0, st, *a));
     });
   } else {
-    IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL(k_router_fwd<DCH>, dim3(nsl, a->R), dim3(256), 0, st, *a)); });
+    // stream batch: 1 for a single stream (no extra registers), else 8 (4 at d > 512)
+    if (a->S == 1) IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<DCH, 1>), dim3(nsl, a->R), dim3(256), 0, st, *a)); });
+    else if (a->d <= 256) IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<1, 8>), dim3(nsl, a->R), dim3(256), 0, st, *a));
+    else if (a->d <= 512) IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<2, 8>), dim3(nsl, a->R), dim3(256), 0, st, *a));
+    else IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<4, 4>), dim3(nsl, a->R), dim3(256), 0, st, *a));
   }
   IC_LAUNCH_CHECK("ic_router_fwd");
   return IC_OK;
