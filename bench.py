@@ -70,6 +70,18 @@ def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
     return table.get(kernel, 0.0)
 
 
+def pmc_traffic(kernel: str, cfg_name: str):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
+    command (profiles/r01_pmc_traffic.json; PMC collection serialises kernels, so it is a
+    separate run, never the timed one).  None when no measurement is on file for the config."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if cfg_name != "10m" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        k = json.load(f).get("kernels", {}).get(kernel)
+    return k["traffic_bytes_per_launch"] if k else None
+
+
 def cpu_baseline(cfg_name: str, B: int, T: int, seed: int):
     """Reference-shaped oracle train_step on the host cores (1 warm-up + 2 timed steps)."""
     from oracle import model as OM
@@ -207,7 +219,7 @@ def main():
             avg_s = ms / launches * 1e-3
             achieved = ab / avg_s / 1e9
             roof = {"bound": "hbm", "kernel": "k_" + name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, args.config), "launches": launches,
                     "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ab,
                     "units_per_launch": {"active_regions": st["n"], "active_edges": st["e"]},
                     "library_kernel_ms_per_step": lib_ms / (1 if survey else args.steps),
