@@ -115,6 +115,28 @@ __device__ __forceinline__ void zero_frag(RowFrag<DCH>& f) {
   for (int j = 0; j < DCH; ++j) f.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// g += slab[0] + slab[1] + ... (rows `stride` floats apart), added in slab order, with up to
+// eight row loads in flight at a time (a serial load-add chain costs a memory round trip each).
+template <int DCH>
+__device__ __forceinline__ void sum_slabs(RowFrag<DCH>& g, const float* __restrict__ first, size_t stride,
+                                          int nslab, int d, int lane) {
+  for (int s0 = 0; s0 < nslab; s0 += 8) {
+    RowFrag<DCH> t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < nslab) load_row(t[u], first + (size_t)(s0 + u) * stride, d, lane);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u < nslab) {
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          g.v[j].x += t[u].v[j].x; g.v[j].y += t[u].v[j].y; g.v[j].z += t[u].v[j].z; g.v[j].w += t[u].v[j].w;
+        }
+      }
+    }
+  }
+}
+
 // Dispatch on the number of 256-column chunks a row needs (d <= 1024).
 #define IC_DISPATCH_DCH(d, ...)                    \
   do {                                             \

@@ -227,15 +227,9 @@ __global__ __launch_bounds__(256) void k_region_mid_bwd(ic_region_bwd_args b, in
   if (row >= SR || !a.mask[row]) return;
   const int d = a.d, r = row % a.R;
   const size_t off = (size_t)row * d;
-  RowFrag<DCH> g, t;
+  RowFrag<DCH> g;
   zero_frag(g);
-  for (int sl = 0; sl < nslab; ++sl) {
-    load_row(t, b.slab + ((size_t)sl * SR + row) * d, d, lane);
-#pragma unroll
-    for (int j = 0; j < DCH; ++j) {
-      g.v[j].x += t.v[j].x; g.v[j].y += t.v[j].y; g.v[j].z += t.v[j].z; g.v[j].w += t.v[j].w;
-    }
-  }
+  sum_slabs(g, b.slab + (size_t)row * d, (size_t)SR * d, nslab, d, lane);
   if (a.flags & IC_F_RT) {
     // g currently holds d/d dir (already scaled by radius'); region.py:219-235
     RowFrag<DCH> y;
@@ -309,11 +303,10 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
     const float steps = (float)(a.dt[row] + 1);
     RowFrag<DCH> acc;
     zero_frag(acc);
-#pragma unroll
-    for (int p = 0; p < RPW / 2; ++p) {
-      const int chr = row0 + 2 * p + (lane & 1);
-      const bool valid = chr < d;      // pairs are valid or invalid together (d even)
-      const int ch = valid ? chr : 0;  // clamp loads
+    {  // lane l < RPW owns channel row0 + l: every operand of the wave's rows in ONE batch of loads
+      const int chr = row0 + (lane < RPW ? lane : 0);
+      const bool valid = lane < RPW && chr < d;  // rotation pairs (even, odd lane) are valid together
+      const int ch = valid ? chr : 0;            // clamp loads
       const size_t idx = off + ch;
       // ---- recompute the forward for this channel
       const float rd = a.raw_decay[(size_t)r * d + ch];
@@ -392,7 +385,7 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
         const float c = cosf(th), sn = sinf(th);
         g_vraw = (lane & 1) ? (-g_vo * sn + g_v * c) : (g_v * c + g_vo * sn);
       }
-      if (valid && lane < 2) {
+      if (valid) {
         b.gnum[idx] = g_numd * lam;
         b.gden[idx] = g_dend * lam;
         if (afd) {
@@ -406,15 +399,13 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
         tg[d + ch] = g_k;
         tg[2 * d + ch] = g_vraw;
       }
-      // broadcast both channels of the pair and accumulate W^T g
+      // broadcast each channel's gradients and accumulate W^T g (rows past d hold zero weights)
+      const float z_r = valid ? g_rpre : 0.f, z_k = valid ? g_k : 0.f, z_v = valid ? g_vraw : 0.f;
 #pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {
-        const float br = valid ? __shfl(g_rpre, q2, 64) : 0.f;
-        const float bk = valid ? __shfl(g_k, q2, 64) : 0.f;
-        const float bv = valid ? __shfl(g_vraw, q2, 64) : 0.f;
-        axpy_frag(acc, br, wr[2 * p + q2]);
-        axpy_frag(acc, bk, wk[2 * p + q2]);
-        axpy_frag(acc, bv, wv[2 * p + q2]);
+      for (int q2 = 0; q2 < RPW; ++q2) {
+        axpy_frag(acc, __shfl(z_r, q2, 64), wr[q2]);
+        axpy_frag(acc, __shfl(z_k, q2, 64), wk[q2]);
+        axpy_frag(acc, __shfl(z_v, q2, 64), wv[q2]);
       }
     }
 #pragma unroll
@@ -452,13 +443,7 @@ __global__ __launch_bounds__(256) void k_region_pro_bwd(ic_region_bwd_args b, in
   const float inv_d = 1.0f / (float)d;
   RowFrag<DCH> g, t, u, w;
   load_row(g, b.ghpre + off, d, lane);  // residual path h = x + ...
-  for (int sl = 0; sl < nslab; ++sl) {
-    load_row(t, b.slab + ((size_t)sl * SR + row) * d, d, lane);
-#pragma unroll
-    for (int j = 0; j < DCH; ++j) {
-      g.v[j].x += t.v[j].x; g.v[j].y += t.v[j].y; g.v[j].z += t.v[j].z; g.v[j].w += t.v[j].w;
-    }
-  }
+  sum_slabs(g, b.slab + (size_t)row * d, (size_t)SR * d, nslab, d, lane);
   load_row(t, a.x + off, d, lane);
   store_row(t, b.tape_x + off, d, lane);
   // ---- region norm: x = nw * u1 * inv1

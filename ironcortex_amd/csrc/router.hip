@@ -190,8 +190,9 @@ __global__ __launch_bounds__(256) void k_router_combine(ic_router_args a) {
 // ---------------------------------------------------------------- backward: per-destination stage
 // Produces, for every active edge, the gradient w.r.t. the biased message (tape_gmsg), and in
 // precision mode the key/query gradients and the direct d/dH_dst term.
+// d > 256: the edges are walked one at a time (the all-at-once variant below would spill).
 template <int DCH>
-__global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
+__global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_args b) {
   const ic_router_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
@@ -271,6 +272,116 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
                               g_mah * res.v[j].y * res.v[j].y * ic_softplus_grad(P.v[j].y),
                               g_mah * res.v[j].z * res.v[j].z * ic_softplus_grad(P.v[j].z),
                               g_mah * res.v[j].w * res.v[j].w * ic_softplus_grad(P.v[j].w));
+      }
+      store_row(gm, b.tape_gmsg + eo, d, lane);
+      store_row(gk, b.tape_gkey + eo, d, lane);
+      store_row(gP, b.g_rawP_rows + eo, d, lane);
+    }
+  }
+  store_row(gHd, b.gHd + (size_t)row * d, d, lane);
+  store_row(gq, b.tape_gq + (size_t)row * d, d, lane);
+}
+
+// d <= 256: every operand of a destination's active edges is requested up front.
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
+  const ic_router_args& a = b.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  const int d = a.d, s = row / a.R, r = row % a.R;
+  const int e0 = a.dst_off[r], deg = a.dst_off[r + 1] - e0;  // <= 8, checked on the host
+  const bool prec = a.flags & IC_RF_PRECISION;
+  RowFrag<DCH> G, t;
+  load_row(G, b.gM + (size_t)row * d, d, lane);
+  load_row(t, a.H + (size_t)row * d, d, lane);
+  // activity of the incoming edges: wave-uniform loads, all requested together
+  bool act[8];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    act[i] = i < deg && a.mask_prev[s * a.R + a.src[e0 + (i < deg ? i : 0)]] != 0;
+    any |= act[i];
+  }
+  store_row(t, b.tape_H + (size_t)row * d, d, lane);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < deg) {
+      const int e = e0 + i;
+      if (lane == 0) b.tape_eact[(size_t)s * a.E + e] = act[i] ? 1 : 0;
+      if (act[i] && !prec) store_row(G, b.tape_gmsg + ((size_t)s * a.E + e) * d, d, lane);
+    }
+  }
+  if (!prec) return;
+  if (lane == 0) b.tape_qact[row] = any ? 1 : 0;
+  RowFrag<DCH> gHd, gq;
+  zero_frag(gHd);
+  zero_frag(gq);
+  if (any) {
+    RowFrag<DCH> hd = t, q, m[8], k[8], P[8];
+    load_row(q, a.q + (size_t)row * d, d, lane);
+    float w[8];
+    // every operand of every active edge is requested before the first reduction waits
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      w[i] = 0.f;
+      if (act[i]) {
+        const int e = e0 + i;
+        const size_t eo = ((size_t)s * a.E + e) * d;
+        w[i] = a.wgt[(size_t)s * a.E + e];
+        load_row(m[i], a.msg + eo, d, lane);
+        load_row(k[i], a.keyv + eo, d, lane);
+        load_row(P[i], a.raw_P + (size_t)a.widx[e] * d, d, lane);
+      }
+    }
+    const float sqrt_d = sqrtf((float)d);
+    // pass 1: g_w and the softmax inner product
+    float gw[8], inner = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      gw[i] = 0.f;
+      if (act[i]) {
+        gw[i] = wave_sum(dot_frag(G, m[i]));
+        inner += w[i] * gw[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (!act[i]) continue;
+      const size_t eo = ((size_t)s * a.E + e0 + i) * d;
+      const float g_lw = w[i] * (gw[i] - inner);
+      // recompute the un-clamped mahalanobis term
+      float part = 0.f;
+      RowFrag<DCH> res, sp;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        res.v[j] = make_float4(m[i].v[j].x - hd.v[j].x, m[i].v[j].y - hd.v[j].y, m[i].v[j].z - hd.v[j].z,
+                               m[i].v[j].w - hd.v[j].w);
+        sp.v[j] = make_float4(ic_softplus(P[i].v[j].x), ic_softplus(P[i].v[j].y), ic_softplus(P[i].v[j].z),
+                              ic_softplus(P[i].v[j].w));
+        const int c = 4 * lane + 256 * j;
+        if (c < d)
+          part += (res.v[j].x * res.v[j].x) * sp.v[j].x + (res.v[j].y * res.v[j].y) * sp.v[j].y +
+                  (res.v[j].z * res.v[j].z) * sp.v[j].z + (res.v[j].w * res.v[j].w) * sp.v[j].w;
+      }
+      const float mahraw = wave_sum(part);
+      const float g_mah = (mahraw <= IC_MAX_EXP / 0.5f) ? -0.5f * g_lw : 0.f;
+      const float g_sc = g_lw / sqrt_d;
+      RowFrag<DCH> gm, gk, gP;
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        float4 gr = make_float4(g_mah * 2.f * res.v[j].x * sp.v[j].x, g_mah * 2.f * res.v[j].y * sp.v[j].y,
+                                g_mah * 2.f * res.v[j].z * sp.v[j].z, g_mah * 2.f * res.v[j].w * sp.v[j].w);
+        gm.v[j] = make_float4(w[i] * G.v[j].x + gr.x, w[i] * G.v[j].y + gr.y, w[i] * G.v[j].z + gr.z,
+                              w[i] * G.v[j].w + gr.w);
+        gHd.v[j].x -= gr.x; gHd.v[j].y -= gr.y; gHd.v[j].z -= gr.z; gHd.v[j].w -= gr.w;
+        gk.v[j] = make_float4(g_sc * q.v[j].x, g_sc * q.v[j].y, g_sc * q.v[j].z, g_sc * q.v[j].w);
+        gq.v[j].x += g_sc * k[i].v[j].x; gq.v[j].y += g_sc * k[i].v[j].y;
+        gq.v[j].z += g_sc * k[i].v[j].z; gq.v[j].w += g_sc * k[i].v[j].w;
+        gP.v[j] = make_float4(g_mah * res.v[j].x * res.v[j].x * ic_softplus_grad(P[i].v[j].x),
+                              g_mah * res.v[j].y * res.v[j].y * ic_softplus_grad(P[i].v[j].y),
+                              g_mah * res.v[j].z * res.v[j].z * ic_softplus_grad(P[i].v[j].z),
+                              g_mah * res.v[j].w * res.v[j].w * ic_softplus_grad(P[i].v[j].w));
       }
       store_row(gm, b.tape_gmsg + eo, d, lane);
       store_row(gk, b.tape_gkey + eo, d, lane);
@@ -384,30 +495,16 @@ __global__ __launch_bounds__(256) void k_router_gather_bwd(ic_router_bwd_args b,
   const int d = a.d, s = row / a.R, r = row % a.R;
   const int SE = a.S * a.E, SR = a.S * a.R;
   const bool prec = a.flags & IC_RF_PRECISION;
-  RowFrag<DCH> g, t;
+  RowFrag<DCH> g;
   zero_frag(g);
   if (prec) {
     load_row(g, b.gHd + (size_t)row * d, d, lane);
-    if (b.tape_qact[row]) {
-      for (int sl = 0; sl < nslab; ++sl) {
-        load_row(t, b.slab_q + ((size_t)sl * SR + row) * d, d, lane);
-#pragma unroll
-        for (int j = 0; j < DCH; ++j) {
-          g.v[j].x += t.v[j].x; g.v[j].y += t.v[j].y; g.v[j].z += t.v[j].z; g.v[j].w += t.v[j].w;
-        }
-      }
-    }
+    if (b.tape_qact[row]) sum_slabs(g, b.slab_q + (size_t)row * d, (size_t)SR * d, nslab, d, lane);
   }
   if (a.mask_prev[row]) {
     for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
       const int e = b.src_edges[i];
-      for (int sl = 0; sl < nslab; ++sl) {
-        load_row(t, b.slab + ((size_t)sl * SE + s * a.E + e) * d, d, lane);
-#pragma unroll
-        for (int j = 0; j < DCH; ++j) {
-          g.v[j].x += t.v[j].x; g.v[j].y += t.v[j].y; g.v[j].z += t.v[j].z; g.v[j].w += t.v[j].w;
-        }
-      }
+      sum_slabs(g, b.slab + ((size_t)s * a.E + e) * d, (size_t)SE * d, nslab, d, lane);
     }
   }
   store_row(g, b.gH + (size_t)row * d, d, lane);
@@ -569,12 +666,12 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else if (a->d <= 512) {
     constexpr int DCH = 2;
-    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b));
     if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else {
     constexpr int DCH = 4;
-    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b));
     if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   }
