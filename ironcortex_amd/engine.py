@@ -80,6 +80,11 @@ class LoopEngine:
     def __init__(self, model):
         self.model = model
         self.enabled = True
+        # Side stream for the branch-parallel part of an outer iteration (gate/router of the later
+        # branches, heads/verifier of the earlier ones).  Off: measured on MI355X it LOSES 3 ms per
+        # train_step (loop forward 26.8 -> 30.0 ms) -- the three cross-stream event waits per
+        # iteration cost more than the ~9 launches they take off the critical path.
+        self.two_streams = False
         self._arena: Optional[StepArena] = None
         self._arena_key = None
         self._ws = None
@@ -226,32 +231,38 @@ class LoopEngine:
         parent: List[int] = []
         step_pos_l: List[float] = []
 
-        def step(par: int, step_k: int, u_mean: float, burst: int) -> int:
-            """One inner step whose H input is the output of step `par` (-1: the loop's H_prev)."""
+        def front(par: int, step_k: int, u_mean: float, burst: int, stream) -> int:
+            """Gate + router of a new inner step whose H input is the output of step `par` (-1: the
+            loop's H_prev), on `stream`.  Returns the step id; region(id) must follow."""
             i = len(parent)
             a = i0 + i
             if par < 0:
                 h_in, mk_in = H0.data_ptr(), mask0.data_ptr()
             else:
                 h_in, mk_in = CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
-            mask_p = CP["mask"] + a * CS["mask"]
             ga.H, ga.t5, ga.t6 = h_in, w5 * float(gate.value_bias), w6 * float(u_mean)
             ga.k_total = max(0, cfg.k_active + burst)
-            ga.scores, ga.mask = CP["scores"] + a * CS["scores"], mask_p
-            rc = g_scores(ga_ref, st) or g_select(ga_ref, st)
+            ga.scores, ga.mask = CP["scores"] + a * CS["scores"], CP["mask"] + a * CS["mask"]
+            rc = g_scores(ga_ref, stream) or g_select(ga_ref, stream)
             if rc:
                 check(rc, "ic_gate")
-            M_p = CP["M"] + a * CS["M"]
             if E > 0:
-                ra.H, ra.mask_prev, ra.M = h_in, mk_in, M_p
+                ra.H, ra.mask_prev, ra.M = h_in, mk_in, CP["M"] + a * CS["M"]
                 for k in rsaved:
                     setattr(ra, k, CP[k] + a * CS[k])
-                rc = r_fwd(ra_ref, st)
+                rc = r_fwd(ra_ref, stream)
                 if rc:
                     check(rc, "ic_router_fwd")
             # (E == 0: M stays at the zeros the arena was created with)
-            sp = float(step_k) / denom
-            fa.step_pos, fa.M, fa.mask = sp, M_p, mask_p
+            parent.append(par)
+            step_pos_l.append(float(step_k) / denom)
+            m.counters["inner_steps"] += 1
+            return i
+
+        def region(i: int, stream) -> None:
+            """Region phase of step i (state chained from the previously executed step)."""
+            a = i0 + i
+            fa.step_pos, fa.M, fa.mask = step_pos_l[i], CP["M"] + a * CS["M"], CP["mask"] + a * CS["mask"]
             fa.num, fa.den, fa.dt = state["num"], state["den"], state["dt"]
             fa.var, fa.surprise = state["var"], state["surprise"]
             fa.pred, fa.radius, fa.radius_var = state["pred"], state["radius"], state["radius_var"]
@@ -262,12 +273,13 @@ class LoopEngine:
                 state[k] = p
             for k in saved:
                 setattr(fa, k, CP[k] + a * CS[k])
-            rc = p_fwd(fa_ref, st)
+            rc = p_fwd(fa_ref, stream)
             if rc:
                 check(rc, "ic_region_phase_fwd")
-            parent.append(par)
-            step_pos_l.append(sp)
-            m.counters["inner_steps"] += 1
+
+        def step(par: int, step_k: int, u_mean: float, burst: int) -> int:
+            i = front(par, step_k, u_mean, burst, st)
+            region(i, st)
             return i
 
         Hf, Mf = chunk.fields["H"], chunk.fields["mask"]
@@ -277,7 +289,7 @@ class LoopEngine:
         ptr_of = lambda i: ((CP["H"] + (i0 + i) * CS["H"], CP["mask"] + (i0 + i) * CS["mask"]) if i >= 0
                             else (H0p, mask0p))
         with torch.no_grad():
-            best, last_step, traces = self._drive(step, ptr_of, H_of, K_inner, dev, chunk, i0, H0, mask0)
+            best, last_step, traces = self._drive((step, front, region), ptr_of, H_of, K_inner, dev, chunk, i0, H0, mask0)
         n = len(parent)
         last_logits = (chunk.fields["logits"][i0 + last_step].clone() if last_step >= 0
                        else torch.zeros(m.V, device=dev))
@@ -342,13 +354,8 @@ class LoopEngine:
             return hs
         R, d, V, Kf = m.R, m.d, m.V, m.lm_head.Kf
         z = lambda *s: torch.zeros(*s, device=dev)
-        buf = dict(z=z(Kf + Kf * V), per_region=z(R, V), probs=z(V), ls=z(64), aux=z(4), ws_prev=z(d), motor=z(d),
-                   p_h=z(d), p=z(d), g_h=z(2 * d), g=z(d), c_h=z(2 * d))
+        buf = dict(ls=z(64), ws_prev=z(d), motor=z(d), p_h=z(d), p=z(d), g_h=z(2 * d), g=z(d), c_h=z(2 * d))
         P = {k: t.data_ptr() for k, t in buf.items()}
-        ha = new("ic_heads_args", R=R, d=d, V=V, Kf=Kf, n_slots=m.work.slots.shape[0], motor_idx=m.io_idxs["motor"],
-                 kwta_k=max(1, d // 4), lm_gate_W=m.lm_head.gate.weight, lm_gate_b=m.lm_head.gate.bias,
-                 lm_W=hf.stacked("facet_W"), lm_b=hf.stacked("facet_b"), rh_W=hf.stacked("rh_W"),
-                 rh_b=hf.stacked("rh_b"), z=buf["z"], per_region=buf["per_region"], probs=buf["probs"])
         G = CLASSES["ic_gemv_desc"]
 
         def desc(g, lin_, xs, y, act, ln=None):
@@ -361,6 +368,32 @@ class LoopEngine:
                 g.ln_g, g.ln_b, g.ln_eps = ln.weight.data_ptr(), ln.bias.data_ptr(), ln.eps
             assert lin_.weight.shape[1] == sum(n for _, n in xs) and lin_.weight.is_contiguous()
 
+        # one set of head scratch + structs per branch: branch b's heads may run on the side stream
+        # while branch b+1's run on the main one
+        nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
+        has, vers, bbufs = [], [], []
+        for _b in range(nb):
+            bb = dict(z=z(Kf + Kf * V), per_region=z(R, V), probs=z(V), aux=z(4))
+            ha = new("ic_heads_args", R=R, d=d, V=V, Kf=Kf, n_slots=m.work.slots.shape[0], motor_idx=m.io_idxs["motor"],
+                     kwta_k=max(1, d // 4), lm_gate_W=m.lm_head.gate.weight, lm_gate_b=m.lm_head.gate.bias,
+                     lm_W=hf.stacked("facet_W"), lm_b=hf.stacked("facet_b"), rh_W=hf.stacked("rh_W"),
+                     rh_b=hf.stacked("rh_b"), z=bb["z"], per_region=bb["per_region"], probs=bb["probs"])
+            ver = None
+            if m.verify is not None:
+                ver = (G * 3)()
+                silu = ENUMS["IC_ACT_SILU"]
+                ln, l1, l2, l3 = m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]
+                hid = l1.weight.shape[0]
+                bb["h1"], bb["h2"] = z(hid), z(hid)
+                desc(ver[0], l1, [(0, d), (bb["probs"].data_ptr(), V), (bb["aux"].data_ptr(), m.verify.aux_dim)],
+                     bb["h1"].data_ptr(), silu, ln)  # energy.py:17-30
+                desc(ver[1], l2, [(bb["h1"].data_ptr(), hid)], bb["h2"].data_ptr(), silu)
+                desc(ver[2], l3, [(bb["h2"].data_ptr(), hid)], 0, ENUMS["IC_ACT_NONE"])
+            has.append(ha); vers.append(ver); bbufs.append(bb)
+        buf.update({k: v for k, v in bbufs[0].items()})  # branch 0's scratch under the plain names
+        P.update({k: t.data_ptr() for k, t in bbufs[0].items()})
+        ha, ver = has[0], vers[0]
+
         steer = None
         if m.plan is not None:
             steer = (G * 6)()
@@ -371,47 +404,46 @@ class LoopEngine:
             desc(steer[3], mods[4], [(P["g_h"], 2 * d)], P["g"], none)
             desc(steer[4], mods[5], [(P["ws_prev"], d), (P["g"], d)], P["c_h"], gelu)  # heads.py:69-70
             desc(steer[5], mods[6], [(P["c_h"], 2 * d)], P["ls"] + 40 * 4, none)
-        ver = None
-        if m.verify is not None:
-            ver = (G * 3)()
-            silu = ENUMS["IC_ACT_SILU"]
-            ln, l1, l2, l3 = m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]
-            hid = l1.weight.shape[0]
-            buf["h1"], buf["h2"] = z(hid), z(hid)
-            P["h1"], P["h2"] = buf["h1"].data_ptr(), buf["h2"].data_ptr()
-            desc(ver[0], l1, [(0, d), (P["probs"], V), (P["aux"], m.verify.aux_dim)], P["h1"], silu, ln)  # energy.py:17-30
-            desc(ver[1], l2, [(P["h1"], hid)], P["h2"], silu)
-            desc(ver[2], l3, [(P["h2"], hid)], 0, ENUMS["IC_ACT_NONE"])
         sa = new("ic_steer_args", R=R, d=d, motor_idx=m.io_idxs["motor"], ws_prev=buf["ws_prev"], motor=buf["motor"])
-        self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods)
+        side = torch.cuda.Stream(device=dev) if nb > 1 else None
+        ev = lambda n: [torch.cuda.Event() for _ in range(n)]
+        self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods, has=has, vers=vers,
+                        bbufs=bbufs, side=side, ev_front=ev(nb), ev_reg=ev(nb), ev_side=torch.cuda.Event())
         return self._hs
 
-    def _drive(self, step, ptr_of, H_of, K_inner, dev, chunk, i0, H0, mask0):
-        """The control flow of reference model.py:329-460 over step ids, heads on the HIP library."""
+    def _drive(self, steps, ptr_of, H_of, K_inner, dev, chunk, i0, H0, mask0):
+        """The control flow of reference model.py:329-460 over step ids, heads on the HIP library.
+
+        Two streams: within an outer iteration the branches are chained only through the region
+        state, so the side stream runs gate + router of the later branches and heads + verifier
+        of the earlier ones while the main stream runs the region phases back to back."""
+        step, front, region = steps
         m = self.model
         cfg, gate = m.cfg, m.gate
         L, st = lib(), stream_handle()
         hs = self._heads_setup(dev)
-        ha, ver, steer, sa, P, ls = hs["ha"], hs["ver"], hs["steer"], hs["sa"], hs["P"], hs["buf"]["ls"]
-        ha_ref, sa_ref = ctypes.byref(ha), ctypes.byref(sa)
+        has, vers, bbufs = hs["has"], hs["vers"], hs["bbufs"]
+        steer, sa, P, ls = hs["steer"], hs["sa"], hs["P"], hs["buf"]["ls"]
+        sa_ref = ctypes.byref(sa)
         d, motor = m.d, m.io_idxs["motor"]
         CP, CS = chunk.ptr, chunk.stride
         afd = "surprise_o" in CP
-        aux_on = ver is not None and m.verify.aux_dim > 0
+        aux_on = vers[0] is not None and m.verify.aux_dim > 0
         if aux_on:  # model.py:396-404: [mixer energy, mean surprise (written per step), attention entropy]
             ent = getattr(m.local_mix.attn, "last_attn_entropy", None)
-            aux = hs["buf"]["aux"]
-            aux[0] = m.local_mix.last_energy.detach()
-            aux[2] = ent.detach() if ent is not None else 0.0
-            ha.aux_surprise = P["aux"] + 4
-        else:
-            ha.aux_surprise = None
+            a02 = torch.stack([m.local_mix.last_energy.detach().reshape(()),
+                               (ent.detach().reshape(()).to(dev) if ent is not None else torch.zeros((), device=dev))])
+            for bb in bbufs:
+                bb["aux"][0::2] = a02
+        for ha, bb in zip(has, bbufs):
+            ha.aux_surprise = bb["aux"].data_ptr() + 4 if aux_on else None
         slots0 = m.work.slots.detach().contiguous()
         slots_ptr = lambda i: CP["slots"] + (i0 + i) * CS["slots"] if i >= 0 else slots0.data_ptr()
         lsp = P["ls"]
         heads_fwd, chain, vscore, steer_sel = L.ic_heads_fwd, L.ic_gemv_chain, L.ic_verify_score, L.ic_steer_select
 
-        def heads(cur: int, par: int, slots_from: int, b: int) -> None:
+        def heads(cur: int, par: int, slots_from: int, b: int, stream) -> None:
+            ha = has[b]
             a = i0 + cur
             ha.H, ha.mask = CP["H"] + a * CS["H"], CP["mask"] + a * CS["mask"]
             ha.H_par = ptr_of(par)[0]
@@ -419,13 +451,21 @@ class LoopEngine:
             ha.surprise = CP["surprise_o"] + a * CS["surprise_o"] if afd else None
             ha.logits = CP["logits"] + a * CS["logits"]
             ha.stats = lsp + (8 + 4 * b) * 4
-            rc = heads_fwd(ha_ref, st)
+            rc = heads_fwd(ctypes.byref(ha), stream)
             if rc:
                 check(rc, "ic_heads_fwd")
 
+        def verify(cur: int, b: int, stream) -> None:
+            ver = vers[b]
+            ver[0].x0 = CP["H"] + (i0 + cur) * CS["H"] + motor * d * 4
+            ver[2].y = lsp + (48 + b) * 4
+            rc = vscore(ver, 3, lsp + (8 + 4 * b) * 4, lsp + b * 4, stream)
+            if rc:
+                check(rc, "ic_verify_score")
+
         last = -1
         traces: List[torch.Tensor] = []
-        if not cfg.train_deterministic_inner_loop and (ver is None or steer is None):
+        if not cfg.train_deterministic_inner_loop and (vers[0] is None or steer is None):
             raise RuntimeError("the branching reasoning loop needs the planner, critic and energy verifier "
                                "(reference model.py:376-438)")
         if cfg.train_deterministic_inner_loop:
@@ -434,16 +474,24 @@ class LoopEngine:
                 gate.value_bias = 0.0
                 par = cur
                 cur = step(par, k, u_mean, 0)
-                heads(cur, par, par, 0)
+                heads(cur, par, par, 0, st)
                 traces.append(H_of(cur).clone())
                 if k + 1 < K_inner:
                     u_mean = float(ls[8])  # utils.py:127-130 of this step's logits (host sync)
             return cur, cur, traces
 
         B_br = cfg.B_br
+        main = torch.cuda.current_stream(dev)
+        side = hs["side"] if self.two_streams else None
+        sx = ctypes.c_void_p(side.cuda_stream) if side is not None else st
+        ev_front, ev_reg, ev_side = hs["ev_front"], hs["ev_reg"], hs["ev_side"]
+        side_busy = False
         branches = [(-1, -1) for _ in range(B_br)]  # (step whose workspace slots, step whose H / mask)
         u_mean = 0.0
         for k in range(K_inner):
+            if side_busy:  # the earlier branches' scores of the previous iteration come from the side stream
+                main.wait_event(ev_side)
+                side_busy = False
             # planner / critic on the best candidate so far, chosen on the device (model.py:371-386)
             sa.n_cand = len(branches)
             for c, (_, hstep) in enumerate(branches):
@@ -452,7 +500,7 @@ class LoopEngine:
             rc = steer_sel(sa_ref, st) or chain(steer, 6, st)
             if rc:
                 check(rc, "ic_steer_select/ic_gemv_chain")
-            vals = ls.tolist()  # the one host sync of this outer iteration
+            vals = ls.tolist()  # the one host sync of this outer iteration (everything before it is complete)
             if k > 0:
                 top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
                 branches = [branches[i] for i in top]
@@ -461,19 +509,38 @@ class LoopEngine:
             v_hat = vals[40]
             gate.value_bias = v_hat
             burst = schedule_burst(u_mean, v_hat, m.R)
+            # gate + router: branch 0 on the main stream, the others on the side stream
+            ids = []
+            for b in range(B_br):
+                on_side = side is not None and b > 0
+                ids.append(front(branches[b][1], k, u_mean, burst, sx if on_side else st))
+                if on_side:
+                    ev_front[b].record(side)
+            # region phases back to back on the main stream (they share the state chain);
+            # heads + verifier of every branch but the last on the side stream
             for b in range(B_br):
                 sl, par = branches[b]
-                cur = step(par, k, u_mean, burst)
-                heads(cur, par, sl, b)
-                ver[0].x0 = CP["H"] + (i0 + cur) * CS["H"] + motor * d * 4
-                ver[2].y = lsp + (48 + b) * 4
-                rc = vscore(ver, 3, lsp + (8 + 4 * b) * 4, lsp + b * 4, st)
-                if rc:
-                    check(rc, "ic_verify_score")
+                cur = ids[b]
+                if side is not None and b > 0:
+                    main.wait_event(ev_front[b])
+                region(cur, st)
+                if side is not None and b < B_br - 1:
+                    ev_reg[b].record(main)
+                    side.wait_event(ev_reg[b])
+                    heads(cur, par, sl, b, sx)
+                    verify(cur, b, sx)
+                    side_busy = True
+                else:
+                    heads(cur, par, sl, b, st)
+                    verify(cur, b, st)
                 branches[b] = (cur, cur)
                 last = cur
+            if side_busy:
+                ev_side.record(side)
             if should_halt(None, u_mean, k, K_inner):
                 break
+        if side_busy:
+            main.wait_event(ev_side)
         vals = ls.tolist()
         top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
         branches = [branches[i] for i in top]

@@ -9,7 +9,7 @@ torch.manual_seed(0); random.seed(0)
 R = cfg.R
 m = ic.CortexReasoner(ic.hex_neighbors(R), ic.hex_axial_coords(R), {"sensor": 0, "motor": R - 1}, cfg).to(dev)
 opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
-toks = torch.randint(0, 255, (4, 256), device=dev)
+toks = torch.randint(0, 255, (8, 256), device=dev)
 ic.train_step(m, opt, toks, ic.LossWeights(), dev)
 pr = cProfile.Profile()
 pr.enable()
@@ -18,5 +18,5 @@ torch.cuda.synchronize()
 pr.disable()
 for key in ("tottime", "cumulative"):
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(28)
-    print(s.getvalue()[:6000])
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
+    print(s.getvalue()[:9000])
