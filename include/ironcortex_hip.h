@@ -249,6 +249,9 @@ int ic_gate_scores(const ic_gate_args* a, ic_stream_t stream);
 /* Gate.select_k + nms_topk (gate.py:70-87, utils.py:107-124).  Total order: score
  * descending, index ascending (stable); quirks of the greedy walk are reproduced. */
 int ic_gate_select(const ic_gate_args* a, ic_stream_t stream);
+/* ic_gate_scores followed by ic_gate_select; ONE launch when R <= 64 (the selecting workgroup
+ * computes the scores of its stream itself). */
+int ic_gate_fwd(const ic_gate_args* a, ic_stream_t stream);
 
 /* ------------------------------------------------------------------ primitives
  * KWTA (utils.py:38-60) on `rows` rows of width d: threshold = k-th largest |x|,

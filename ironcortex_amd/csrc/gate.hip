@@ -59,15 +59,12 @@ __global__ __launch_bounds__(256) void k_gate_scores(ic_gate_args a) {
   }
 }
 
-// One workgroup per stream.  Stable descending rank by counting, then the greedy
-// suppression walk on one lane (R <= 1024, the walk stops after k selections).
-__global__ __launch_bounds__(256) void k_gate_select(ic_gate_args a) {
-  __shared__ float sc[1024];
-  __shared__ int order[1024];
-  __shared__ uint8_t supp[1024];
-  const int s = blockIdx.x, R = a.R;
+// Stable descending rank by counting, then the greedy suppression walk on one lane (R <= 1024,
+// the walk stops after k selections).  sc[] holds the stream's scores; all threads call.
+__device__ __forceinline__ void gate_select_body(const ic_gate_args& a, int s, const float* sc, int* order,
+                                                 uint8_t* supp) {
+  const int R = a.R;
   for (int i = threadIdx.x; i < R; i += blockDim.x) {
-    sc[i] = a.scores[s * R + i];
     supp[i] = 0;
     a.mask[s * R + i] = 0;
   }
@@ -101,6 +98,53 @@ __global__ __launch_bounds__(256) void k_gate_select(ic_gate_args a) {
       for (int q = a.nbr_off[i]; q < a.nbr_off[i + 1]; ++q) supp[a.nbr[q]] = 1;
     }
   }
+}
+
+// One workgroup per stream.
+__global__ __launch_bounds__(256) void k_gate_select(ic_gate_args a) {
+  __shared__ float sc[1024];
+  __shared__ int order[1024];
+  __shared__ uint8_t supp[1024];
+  const int s = blockIdx.x;
+  for (int i = threadIdx.x; i < a.R; i += blockDim.x) sc[i] = a.scores[s * a.R + i];
+  __syncthreads();
+  gate_select_body(a, s, sc, order, supp);
+}
+
+// Scores and selection in ONE launch for small region counts: the workgroup of a stream reads
+// its R rows itself (R*d*4 bytes: 10 KB at R=10, one CU is enough) and goes straight on to the
+// walk.  Saves a launch per inner step where launches, not bytes, are the cost.
+template <int DCH>
+__global__ __launch_bounds__(256) void k_gate_fused(ic_gate_args a) {
+  __shared__ float sc[1024];
+  __shared__ int order[1024];
+  __shared__ uint8_t supp[1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x;
+  for (int r = wave; r < a.R; r += 4) {
+    const int row = s * a.R + r;
+    RowFrag<DCH> h;
+    load_row(h, a.H + (size_t)row * a.d, a.d, lane);
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < DCH; ++j)
+      part += (fabsf(h.v[j].x) + fabsf(h.v[j].y)) + (fabsf(h.v[j].z) + fabsf(h.v[j].w));
+    const float content = wave_sum(part) / (float)a.d;
+    if (lane == 0) {
+      const float focus =
+          (a.focus_any && a.focus_any[s] && (r == a.sensor_idx || r == a.motor_idx)) ? 1.0f : 0.0f;
+      float v = a.w1 * content;
+      v = v + a.w2 * a.gain_ema[r];
+      v = v + a.w3 * focus;
+      v = v - a.w4 * a.homeo[r];
+      v = v + a.t5;
+      v = v + a.t6;
+      a.scores[row] = v;
+      sc[r] = v;
+    }
+  }
+  __syncthreads();
+  gate_select_body(a, s, sc, order, supp);
 }
 
 template <int DCH>
@@ -213,6 +257,26 @@ extern "C" int ic_gate_select(const ic_gate_args* a, ic_stream_t stream) {
              "ic_gate_select: io indices out of range");
   IC_TIMED(IC_KID_gate_select, (hipStream_t)stream, hipLaunchKernelGGL(k_gate_select, dim3(a->S), dim3(256), 0, (hipStream_t)stream, *a));
   IC_LAUNCH_CHECK("ic_gate_select");
+  return IC_OK;
+}
+
+extern "C" int ic_gate_fwd(const ic_gate_args* a, ic_stream_t stream) {
+  IC_REQUIRE(a != nullptr, "ic_gate_fwd: NULL args");
+  if (a->R > 64) {  // big maps: scores over the whole chip, then the walk
+    int rc = ic_gate_scores(a, stream);
+    return rc ? rc : ic_gate_select(a, stream);
+  }
+  int rc = check_gate(a, "ic_gate_fwd");
+  if (rc) return rc;
+  IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "ic_gate_fwd: d=%d unsupported", a->d);
+  IC_REQUIRE(a->H && a->gain_ema && a->homeo && a->mask && a->nbr_off && a->nbr, "ic_gate_fwd: NULL pointer");
+  IC_REQUIRE(!a->force_io || (a->sensor_idx >= 0 && a->sensor_idx < a->R && a->motor_idx >= 0 &&
+                              a->motor_idx < a->R),
+             "ic_gate_fwd: io indices out of range");
+  IC_DISPATCH_DCH(a->d, {
+    IC_TIMED(IC_KID_gate_select, (hipStream_t)stream, hipLaunchKernelGGL(k_gate_fused<DCH>, dim3(a->S), dim3(256), 0, (hipStream_t)stream, *a));
+  });
+  IC_LAUNCH_CHECK("ic_gate_fwd");
   return IC_OK;
 }
 

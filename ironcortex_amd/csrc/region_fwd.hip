@@ -14,60 +14,71 @@ namespace {
 
 
 // ---------------------------------------------------------------- prologue (wave per row)
+// x = RMSNorm_r( RMSNorm_in(M[r] (+sensor)) + pred )   (region.py:173-177, model.py:198-204)
+// All operand rows are requested before the first reduction.
+template <int DCH>
+__device__ __forceinline__ void prologue_row(const ic_region_args& a, int row, int lane, RowFrag<DCH>& u1,
+                                             RowFrag<DCH>& x, float& inv0, float& inv1) {
+  const int s = row / a.R, r = row % a.R;
+  const int d = a.d;
+  const float inv_d = 1.0f / (float)d;
+  const bool norm_in = a.flags & IC_F_NORM_IN, pred = a.flags & IC_F_PRED;
+  const bool io = norm_in && a.sensor && (r == a.sensor_idx || r == a.motor_idx);
+  RowFrag<DCH> u, sv, win, p, w;
+  load_row(u, a.M + (size_t)row * d, d, lane);
+  if (io) load_row(sv, a.sensor + (size_t)s * d, d, lane);
+  if (norm_in) load_row(win, a.norm_in_w, d, lane);
+  if (pred) load_row(p, a.pred + (size_t)row * d, d, lane);
+  load_row(w, a.norm_w + (size_t)r * d, d, lane);
+  inv0 = 1.0f;
+  if (norm_in) {
+    if (io) {
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        u.v[j].x += sv.v[j].x; u.v[j].y += sv.v[j].y; u.v[j].z += sv.v[j].z; u.v[j].w += sv.v[j].w;
+      }
+    }
+    const float ss = wave_sum(dot_frag(u, u));
+    const float s0 = sqrtf(ss * inv_d + IC_RMS_EPS);
+    inv0 = 1.0f / s0;
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      u.v[j].x = win.v[j].x * (u.v[j].x / s0); u.v[j].y = win.v[j].y * (u.v[j].y / s0);
+      u.v[j].z = win.v[j].z * (u.v[j].z / s0); u.v[j].w = win.v[j].w * (u.v[j].w / s0);
+    }
+  }
+  if (pred) {
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      u.v[j].x += p.v[j].x; u.v[j].y += p.v[j].y; u.v[j].z += p.v[j].z; u.v[j].w += p.v[j].w;
+    }
+  }
+  u1 = u;
+  const float ss1 = wave_sum(dot_frag(u, u));
+  const float s1 = sqrtf(ss1 * inv_d + IC_RMS_EPS);
+  inv1 = 1.0f / s1;
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    x.v[j].x = w.v[j].x * (u.v[j].x / s1); x.v[j].y = w.v[j].y * (u.v[j].y / s1);
+    x.v[j].z = w.v[j].z * (u.v[j].z / s1); x.v[j].w = w.v[j].w * (u.v[j].w / s1);
+  }
+}
+
 template <int DCH>
 __global__ __launch_bounds__(256) void k_region_pro(ic_region_args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.S * a.R) return;
   if (!a.mask[row]) return;
-  const int s = row / a.R, r = row % a.R;
   const int d = a.d;
-  const float inv_d = 1.0f / (float)d;
-  RowFrag<DCH> u;
-  load_row(u, a.M + (size_t)row * d, d, lane);
-  float inv0 = 1.0f;
-  if (a.flags & IC_F_NORM_IN) {
-    if (a.sensor && (r == a.sensor_idx || r == a.motor_idx)) {
-      RowFrag<DCH> sv;
-      load_row(sv, a.sensor + (size_t)s * d, d, lane);
-#pragma unroll
-      for (int j = 0; j < DCH; ++j) {
-        u.v[j].x += sv.v[j].x; u.v[j].y += sv.v[j].y; u.v[j].z += sv.v[j].z; u.v[j].w += sv.v[j].w;
-      }
-    }
-    float ss = wave_sum(dot_frag(u, u));
-    float s0 = sqrtf(ss * inv_d + IC_RMS_EPS);
-    inv0 = 1.0f / s0;
-    RowFrag<DCH> w;
-    load_row(w, a.norm_in_w, d, lane);
-#pragma unroll
-    for (int j = 0; j < DCH; ++j) {
-      u.v[j].x = w.v[j].x * (u.v[j].x / s0); u.v[j].y = w.v[j].y * (u.v[j].y / s0);
-      u.v[j].z = w.v[j].z * (u.v[j].z / s0); u.v[j].w = w.v[j].w * (u.v[j].w / s0);
-    }
-  }
-  if (a.flags & IC_F_PRED) {
-    RowFrag<DCH> p;
-    load_row(p, a.pred + (size_t)row * d, d, lane);
-#pragma unroll
-    for (int j = 0; j < DCH; ++j) {
-      u.v[j].x += p.v[j].x; u.v[j].y += p.v[j].y; u.v[j].z += p.v[j].z; u.v[j].w += p.v[j].w;
-    }
-  }
-  store_row(u, a.u1 + (size_t)row * d, d, lane);
-  float ss1 = wave_sum(dot_frag(u, u));
-  float s1 = sqrtf(ss1 * inv_d + IC_RMS_EPS);
-  RowFrag<DCH> w;
-  load_row(w, a.norm_w + (size_t)r * d, d, lane);
-#pragma unroll
-  for (int j = 0; j < DCH; ++j) {
-    u.v[j].x = w.v[j].x * (u.v[j].x / s1); u.v[j].y = w.v[j].y * (u.v[j].y / s1);
-    u.v[j].z = w.v[j].z * (u.v[j].z / s1); u.v[j].w = w.v[j].w * (u.v[j].w / s1);
-  }
-  store_row(u, a.x + (size_t)row * d, d, lane);
+  RowFrag<DCH> u1, x;
+  float inv0, inv1;
+  prologue_row(a, row, lane, u1, x, inv0, inv1);
+  store_row(u1, a.u1 + (size_t)row * d, d, lane);
+  store_row(x, a.x + (size_t)row * d, d, lane);
   if (lane == 0) {
     a.inv_s[row * 2 + 0] = inv0;
-    a.inv_s[row * 2 + 1] = 1.0f / s1;
+    a.inv_s[row * 2 + 1] = inv1;
   }
 }
 
@@ -80,7 +91,9 @@ __device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int 
 // ---------------------------------------------------------------- r,k,v GEMVs + state update
 // PP = channel pairs per wave: a workgroup owns 8*PP rows of W_r, W_k, W_v (24*PP KiB at d=256),
 // all loaded up front so every wave keeps 6*PP independent 1 KiB row requests in flight.
-template <int DCH, int PP>
+// FUSE: the prologue is recomputed by every wave instead of being a launch of its own (few
+// streams: the extra row loads are L2 hits, the saved launch is ~6 us).
+template <int DCH, int PP, bool FUSE>
 __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
   const int r = blockIdx.y;
   if (!region_has_work(a.mask, a.S, a.R, r)) return;
@@ -138,7 +151,21 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
   };
   auto request = [&](int s, Ops& o) {
     const int row = s * a.R + r;
-    load_row(o.xv, a.x + (size_t)row * d, d, lane);
+    if (FUSE) {
+      RowFrag<DCH> u1;
+      float inv0, inv1;
+      prologue_row(a, row, lane, u1, o.xv, inv0, inv1);
+      if (blockIdx.x == 0 && wave == 0) {  // saved for the backward / the output projection
+        store_row(u1, a.u1 + (size_t)row * d, d, lane);
+        store_row(o.xv, a.x + (size_t)row * d, d, lane);
+        if (lane == 0) {
+          a.inv_s[row * 2 + 0] = inv0;
+          a.inv_s[row * 2 + 1] = inv1;
+        }
+      }
+    } else {
+      load_row(o.xv, a.x + (size_t)row * d, d, lane);
+    }
     o.steps = (float)(a.dt[row] + 1);
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
@@ -432,10 +459,15 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
   if (a->d > 256 && rpb > 16) rpb = 16;  // register budget at DCH >= 2
   const dim3 gmat(ic_ceil_div(a->d, rpb), a->R);
   const float oma = (float)(1.0 - a->pred_alpha);
+  const bool fuse = a->S <= 2;  // prologue inside rkv
 #define IC_FWD_LAUNCH(PP)                                                                                   \
   IC_DISPATCH_DCH(a->d, {                                                                                   \
-    IC_TIMED(IC_KID_region_pro, st, hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a));           \
-    IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP>), gmat, blk, 0, st, *a));     \
+    if (fuse) {                                                                                             \
+      IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, true>), gmat, blk, 0, st, *a));  \
+    } else {                                                                                                \
+      IC_TIMED(IC_KID_region_pro, st, hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a));         \
+      IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, false>), gmat, blk, 0, st, *a)); \
+    }                                                                                                       \
     IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL((k_region_out<DCH, PP>), gmat, blk, 0, st, *a));     \
     IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma));      \
   })

@@ -207,7 +207,7 @@ class LoopEngine:
         fa.sensor = sens_c.data_ptr()
         fa.last_dir, fa.last_norm = bank.last_dir.data_ptr(), bank.last_norm.data_ptr()
         prec, afd, rt_, use_pred = rspec.precision, bank.afd, bank.rt, bank.use_pred
-        g_scores, g_select = L.ic_gate_scores, L.ic_gate_select
+        g_fwd = L.ic_gate_fwd
         r_fwd, p_fwd = L.ic_router_fwd, L.ic_region_phase_fwd
         ga_ref, ra_ref, fa_ref = ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(fa)
         w5, w6 = gate.w5, gate.w6
@@ -243,7 +243,7 @@ class LoopEngine:
             ga.H, ga.t5, ga.t6 = h_in, w5 * float(gate.value_bias), w6 * float(u_mean)
             ga.k_total = max(0, cfg.k_active + burst)
             ga.scores, ga.mask = CP["scores"] + a * CS["scores"], CP["mask"] + a * CS["mask"]
-            rc = g_scores(ga_ref, stream) or g_select(ga_ref, stream)
+            rc = g_fwd(ga_ref, stream)
             if rc:
                 check(rc, "ic_gate")
             if E > 0:

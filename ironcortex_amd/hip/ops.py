@@ -412,7 +412,8 @@ def gate_scores_select(H: torch.Tensor, gain_ema: torch.Tensor, homeo: torch.Ten
     if scores is None:
         scores = _e(H, S, R)
         a.scores = scores.data_ptr()
-        _call("ic_gate_scores", a)
+        _call("ic_gate_fwd" if select else "ic_gate_scores", a)
+        select = False
     else:
         scores = scores.contiguous()
         a.scores = scores.data_ptr()
