@@ -97,7 +97,7 @@ class LoopEngine:
             return False
         if torch.is_grad_enabled() and logits_need_grad:
             return False
-        if m.cfg.profile or m.cfg.ff_dropout:
+        if m.cfg.profile or m.cfg.ff_dropout or m.router.edge_transform_mode == "factorized":
             return False
         b = m.bank
         if b.S != 1 or b.num.device != H_prev.device:

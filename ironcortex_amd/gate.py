@@ -127,8 +127,14 @@ class Router(nn.Module):
                       "raw_P": list(self.raw_P_dir)}
             self.nW = 6
         elif edge_transform_mode == "factorized":
-            raise NotImplementedError(
-                "edge_transform_mode='factorized' (gate.py:150-159) is not built yet in ironcortex_amd")
+            # msg_e = U (w_e * V h_src)   (gate.py:150-159,278-281): two SHARED d x d matrices, i.e.
+            # plain [E_act,d] x [d,d] GEMMs -- run through rocBLAS (MFMA) from PyTorch, see _route_factorized
+            self.U, self.V = mk(), mk()
+            self.w_edge = nn.ParameterDict({k: nn.Parameter(torch.ones(d)) for k in keys})
+            self.key_lin = nn.ModuleDict({k: mk() for k in keys})
+            self.raw_P_edge = nn.ParameterDict({k: ArenaParameter(torch.zeros(d)) for k in keys})
+            groups = {"key_W": [self.key_lin[k].weight for k in keys], "raw_P": [self.raw_P_edge[k] for k in keys]}
+            self.nW = self.E
         else:
             raise ValueError(f"unknown edge_transform_mode {edge_transform_mode}")
         self.query_lin = nn.ModuleList([mk() for _ in range(R)])
@@ -282,6 +288,8 @@ class Router(nn.Module):
         dev = H.device
         if self._flat.flat.device != dev:
             raise RuntimeError("Router parameters and input are on different devices")
+        if self.edge_transform_mode == "factorized":
+            return torch.stack([self._route_factorized(H[s], mask_prev[s].bool(), reg_coords) for s in range(S)])
         tables = self._edge_tables(reg_coords)
         ebias = self._cached_bias(reg_coords)
         spec = ops.RouterSpec(self.R, self.d, self.E, self.nW, self.enable_precision_routed_messages)
@@ -296,6 +304,37 @@ class Router(nn.Module):
         M = ops.RouterFn.apply(anchor, H, ebias, box)
         self._last_wgt = box.get("wgt")
         return M
+
+    def _route_factorized(self, H: torch.Tensor, mask_prev: torch.Tensor, reg_coords: torch.Tensor) -> torch.Tensor:
+        """Factorised edge transforms for one stream (gate.py:251-335 with :278-281).  The shared
+        U and V make this the one GEMM-shaped mode: [E_act,d] x [d,d] twice, on rocBLAS.  Only the
+        ACTIVE edges' parameters enter the graph (one host read of the active set, as the
+        reference does), so inactive edges keep grad None."""
+        R, d, dev = self.R, self.d, H.device
+        active = mask_prev[self.src_idx].nonzero().flatten().tolist()
+        self._last_wgt = torch.zeros(1, max(self.E, 1), device=dev)[:, : self.E]
+        if not active:
+            return torch.zeros(R, d, device=dev)
+        act = torch.tensor(active, device=dev)
+        src, dst = self.src_idx[act], self.dst_idx[act]
+        keys = [self.edge_keys[e] for e in active]
+        scale = torch.stack([self.w_edge[k] for k in keys])
+        msg = self.U(self.V(H[src]) * scale)
+        if self.fb_alpha != 0.0:
+            msg = msg * self._cached_bias(reg_coords)[act].unsqueeze(-1)
+        weight = None
+        if self.enable_precision_routed_messages:
+            q = torch.stack([self.query_lin[r](H[r]) for r in range(R)])
+            Wk = torch.stack([self.key_lin[k].weight for k in keys])
+            kv = torch.bmm(Wk, H[src].unsqueeze(-1)).squeeze(-1)
+            prec = torch.nn.functional.softplus(torch.stack([self.raw_P_edge[k] for k in keys]))
+            logw = (q[dst] * kv).sum(-1) / math.sqrt(d) - 0.5 * ((msg - H[dst]).pow(2) * prec).sum(-1).clamp_max(80.0)
+            top = torch.full((R,), float("-inf"), device=dev).scatter_reduce(0, dst, logw, reduce="amax")
+            z = torch.zeros(R, device=dev).scatter_add(0, dst, torch.exp(logw - top[dst]))
+            weight = torch.exp(logw - (top + z.clamp_min(EPS_DIV).log())[dst])
+            self._last_wgt = torch.zeros(1, self.E, device=dev).index_put((torch.zeros_like(act), act), weight.detach())
+            msg = weight.unsqueeze(-1) * msg
+        return torch.zeros(R, d, device=dev).index_add(0, dst, msg)
 
     def messages(self, H: torch.Tensor, reg_mask_prev: torch.Tensor, reg_coords: torch.Tensor) -> torch.Tensor:
         """H [R,d], bool [R] -> M [R,d] (gate.py:337-342); both the vectorised and the loop

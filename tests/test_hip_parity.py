@@ -408,14 +408,19 @@ def make_router(name, R, d, mode, prec, t):
             for e, k in enumerate(router.edge_keys):
                 router.W_edge[k].weight.copy_(t["W_edge"][e]); router.key_lin[k].weight.copy_(t["key_W"][e])
                 router.raw_P_edge[k].copy_(t["raw_P"][e])
-        else:
+        elif mode == "by_direction":
             for i in range(6):
                 router.W_dir[i].weight.copy_(t["W_dir"][i]); router.key_lin_dir[i].weight.copy_(t["key_W"][i])
                 router.raw_P_dir[i].copy_(t["raw_P"][i])
+        else:
+            router.U.weight.copy_(t["U"]); router.V.weight.copy_(t["V"])
+            for e, k in enumerate(router.edge_keys):
+                router.w_edge[k].copy_(t["w_edge"][e]); router.key_lin[k].weight.copy_(t["key_W"][e])
+                router.raw_P_edge[k].copy_(t["raw_P"][e])
     return router
 
 
-@pytest.mark.parametrize("ci", [i for i, c in enumerate(gi.ROUTER_CASES) if c[3] != "factorized"])
+@pytest.mark.parametrize("ci", range(len(gi.ROUTER_CASES)))
 def test_router_vs_reference(ci):
     from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
     gold = load("router.npz")
@@ -441,15 +446,22 @@ def test_router_vs_reference(ci):
         src_active = t["mask_prev"][router.src_idx.cpu()]
         for e, k in enumerate(router.edge_keys):
             assert (router.W_edge[k].weight.grad is not None) == bool(src_active[e]), k
-    else:
+    elif mode == "by_direction":
         gclose(torch.stack([getg(l.weight, zeros) for l in router.W_dir]), gold[pre + "g.W_dir"], what="g.W_dir")
+    else:  # factorized: shared U, V on rocBLAS GEMMs + per-edge diagonal
+        gclose(router.U.weight.grad, gold[pre + "g.U"], what="g.U")
+        gclose(router.V.weight.grad, gold[pre + "g.V"], what="g.V")
+        gclose(torch.stack([getg(router.w_edge[k], torch.zeros(d)) for k in router.edge_keys]), gold[pre + "g.w_edge"], what="g.w_edge")
+        src_active = t["mask_prev"][router.src_idx.cpu()]
+        for e, k in enumerate(router.edge_keys):
+            assert (router.w_edge[k].grad is not None) == bool(src_active[e]), k
     if prec:
         w = torch.zeros(E)
         for e, k in enumerate(router.edge_keys):
             w[e] = router.last_weights.get(k, 0.0)
         close(w, gold[pre + "weights"], rtol=5e-5, atol=1e-6, what="weights")
         gclose(torch.stack([getg(l.weight, zeros) for l in router.query_lin]), gold[pre + "g.query_W"], what="g.query")
-        if mode == "per_edge":
+        if mode in ("per_edge", "factorized"):
             gclose(torch.stack([getg(router.key_lin[k].weight, zeros) for k in router.edge_keys]), gold[pre + "g.key_W"], what="g.key")
             gclose(torch.stack([getg(router.raw_P_edge[k], torch.zeros(d)) for k in router.edge_keys]), gold[pre + "g.raw_P"], what="g.rawP")
         else:
