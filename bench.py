@@ -123,13 +123,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if os.environ.get("IC_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dp = None
     if world > 1:
         import torch.distributed as dist
         from ironcortex_amd.parallel import DataParallel
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL over xGMI; IC_DIST_BACKEND=gloo only to rehearse the N>1 code path on a one-GPU box
+        backend = os.environ.get("IC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         dp = DataParallel()
 
     cfg = make_config(args.config)

@@ -75,9 +75,10 @@ class DataParallel:
             flat = torch.cat([p.grad.reshape(-1) for p in live[i:j]])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             flat.div_(self.world)
-            off = 0
+            views, off = [], 0
             for p in live[i:j]:
                 k = p.numel()
-                p.grad.copy_(flat[off:off + k].view_as(p.grad))
+                views.append(flat[off:off + k].view_as(p.grad))
                 off += k
+            torch._foreach_copy_([p.grad for p in live[i:j]], views)  # one multi-tensor launch
             i = j
