@@ -88,7 +88,7 @@ class LoopEngine:
         self._arena: Optional[StepArena] = None
         self._arena_key = None
         self._ws = None
-        self._samples_alive = 0
+        self._state_in_arena = False
 
     # ------------------------------------------------------------------ applicability
     def usable(self, H_prev: torch.Tensor, logits_need_grad: bool) -> bool:
@@ -105,9 +105,23 @@ class LoopEngine:
         return not any(getattr(b, k).requires_grad for k in ("num", "den", "var", "pred", "radius", "radius_var"))
 
     def reset(self) -> None:
-        """Start of a new forward/backward pass: every step slot may be reused."""
+        """Start of a new forward/backward pass: every step slot may be reused.  The bank's state
+        tensors are views of the last loop's final slot until now; copy them out first."""
+        self._rescue_state()
         if self._arena is not None:
             self._arena.reset()
+
+    def _rescue_state(self) -> None:
+        if not self._state_in_arena:
+            return
+        m = self.model
+        b = m.bank
+        for k in ("num", "den", "dt", "var", "surprise", "pred", "radius", "radius_var"):
+            setattr(b, k, getattr(b, k).clone())
+        if m.router._last_wgt is not None:
+            m.router._last_wgt = m.router._last_wgt.clone()
+        m.work.slots = m.work.slots.clone()
+        self._state_in_arena = False
 
     # ------------------------------------------------------------------ storage
     def _shapes(self):
@@ -175,7 +189,7 @@ class LoopEngine:
         n_max = K_inner * (1 if cfg.train_deterministic_inner_loop else cfg.B_br)
         arena = self._get_arena(dev, n_max)
         if not grad:
-            arena.reset()  # nothing is kept from a no-grad loop: outputs are cloned below
+            self.reset()  # nothing is kept from a no-grad loop: outputs are cloned below
         chunk, i0 = arena.reserve(max(1, n_max), dev)
         CP, CS = chunk.ptr, chunk.stride
 
@@ -294,22 +308,23 @@ class LoopEngine:
         last_logits = (chunk.fields["logits"][i0 + last_step].clone() if last_step >= 0
                        else torch.zeros(m.V, device=dev))
         if best >= 0:
-            m.work.slots = chunk.fields["slots"][i0 + best].clone()
+            m.work.slots = chunk.fields["slots"][i0 + best]
 
-        # ---- hand the state back to the bank (copies: the arena is recycled at the next pass)
-        last = i0 + n - 1
+        # ---- hand the state back to the bank: views of the last slot, copied out by reset()
+        # before the arena is recycled (15 of 16 loops of a train_step never need the copy)
+        li = i0 + n - 1
         f = chunk.fields
         if n > 0:
-            bank.num, bank.den, bank.dt = f["num_o"][last:last + 1].clone(), f["den_o"][last:last + 1].clone(), \
-                f["dt_o"][last:last + 1].clone()
+            bank.num, bank.den, bank.dt = f["num_o"][li:li + 1], f["den_o"][li:li + 1], f["dt_o"][li:li + 1]
             if afd:
-                bank.var, bank.surprise = f["var_o"][last:last + 1].clone(), f["surprise_o"][last:last + 1].clone()
+                bank.var, bank.surprise = f["var_o"][li:li + 1], f["surprise_o"][li:li + 1]
             if use_pred:
-                bank.pred = f["pred_o"][last:last + 1].clone()
+                bank.pred = f["pred_o"][li:li + 1]
             if rt_:
-                bank.radius, bank.radius_var = f["radius_o"][last:last + 1].clone(), f["radius_var_o"][last:last + 1].clone()
+                bank.radius, bank.radius_var = f["radius_o"][li:li + 1], f["radius_var_o"][li:li + 1]
             if prec:
-                router._last_wgt = f["wgt"][last:last + 1, :E].clone()
+                router._last_wgt = f["wgt"][li:li + 1, :E]
+            self._state_in_arena = True
         if m._units is not None and E > 0 and n > 0:
             self._count_units(chunk, i0, parent, mask0)
 
@@ -421,6 +436,7 @@ class LoopEngine:
         m = self.model
         cfg, gate = m.cfg, m.gate
         L, st = lib(), stream_handle()
+        keep = (lambda t: t) if (m._logits_detached and torch.is_grad_enabled()) else (lambda t: t.clone())
         hs = self._heads_setup(dev)
         has, vers, bbufs = hs["has"], hs["vers"], hs["bbufs"]
         steer, sa, P, ls = hs["steer"], hs["sa"], hs["P"], hs["buf"]["ls"]
@@ -475,7 +491,7 @@ class LoopEngine:
                 par = cur
                 cur = step(par, k, u_mean, 0)
                 heads(cur, par, par, 0, st)
-                traces.append(H_of(cur).clone())
+                traces.append(keep(H_of(cur)))
                 if k + 1 < K_inner:
                     u_mean = float(ls[8])  # utils.py:127-130 of this step's logits (host sync)
             return cur, cur, traces
@@ -504,7 +520,7 @@ class LoopEngine:
             if k > 0:
                 top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
                 branches = [branches[i] for i in top]
-                traces.append(H_of(branches[0][1]).clone())
+                traces.append(keep(H_of(branches[0][1])))
                 u_mean = vals[8 + 4 * (B_br - 1)]
             v_hat = vals[40]
             gate.value_bias = v_hat
@@ -544,7 +560,7 @@ class LoopEngine:
         vals = ls.tolist()
         top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
         branches = [branches[i] for i in top]
-        traces.append(H_of(branches[0][1]).clone())
+        traces.append(keep(H_of(branches[0][1])))
         return branches[0][1], last, traces
 
     # ------------------------------------------------------------------ backward
@@ -577,9 +593,13 @@ class LoopEngine:
         if prec:
             zf["g_rawP_rows"] = Ez * d
         Z, zp = {}, {}
+        pad = lambda n: (n + 63) // 64 * 64  # every field starts 256-byte aligned (float4 row stores)
+        zall = torch.zeros(sum(pad(n_r * sz) for sz in zf.values()), device=dev)  # ONE fill for the whole loop
+        zoff = 0
         for k, sz in zf.items():
-            Z[k] = torch.zeros(n_r, sz, device=dev)
+            Z[k] = zall[zoff:zoff + n_r * sz].view(n_r, sz)
             zp[k] = Z[k].data_ptr()
+            zoff += pad(n_r * sz)
         Z["gH"][s.best].copy_(gH_final.reshape(-1))
         has_grad = [False] * n_r
         has_grad[s.best] = True

@@ -220,17 +220,21 @@ class Router(nn.Module):
         return 1.0 + self.fb_alpha * b
 
     def begin_loop(self) -> None:
-        """Inside one reasoning loop the bias parameters are fixed: compute 1 + alpha*b once."""
-        self._bias_cache = "armed"
+        """Inside one reasoning loop the bias parameters are fixed: compute 1 + alpha*b once.
+        With hold_bias set (train_step: all loops of a step feed ONE backward pass) the value is
+        kept from loop to loop until a parameter version changes."""
+        if not (getattr(self, "hold_bias", False) and isinstance(getattr(self, "_bias_cache", None), tuple)):
+            self._bias_cache = "armed"
 
     def end_loop(self) -> None:
-        self._bias_cache = None
+        if not getattr(self, "hold_bias", False):
+            self._bias_cache = None
 
     def _cached_bias(self, reg_coords: torch.Tensor) -> torch.Tensor:
         c = getattr(self, "_bias_cache", None)
         if c is None:
             return self._edge_bias(reg_coords)
-        key = (torch.is_grad_enabled(), self.fb_alpha, self.beta_cos._version)
+        key = (torch.is_grad_enabled(), self.fb_alpha, self.beta_cos._version, self.beta_sin._version)
         if c == "armed" or c[0] != key:
             c = (key, self._edge_bias(reg_coords))
             self._bias_cache = c

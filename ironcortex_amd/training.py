@@ -69,10 +69,13 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     # the loops may run on the LoopEngine (one autograd node per loop)
     model.engine.reset()
     model._logits_detached = True
+    model.router.hold_bias = True  # every loop of this step feeds the one backward pass below
     try:
         H_all, reg_all, logits_all, _tr, energy_all, entropy_all = model.reasoning_loop_batch(tokens_all, cfg.K_inner, focus_all)
     finally:
         model._logits_detached = False
+        model.router.hold_bias = False
+        model.router._bias_cache = None
     H_pos, H_neg = H_all[:B], H_all[B:]
     mask_p, mask_n = reg_all[:B], reg_all[B:]
     logits_pos, logits_neg = logits_all[:B], logits_all[B:]
