@@ -323,6 +323,7 @@ typedef struct ic_heads_args {
   const float* surprise; /* [R] surprise_ema after this step, or NULL */
   float* z;              /* [Kf + Kf*V] scratch: gate pre-activations, then facet outputs */
   float* per_region;     /* [R,V] scratch */
+  float* gsq;            /* [2R] scratch: per-row sums of squares of H and H_par */
   float* logits;         /* [V] */
   float* probs;          /* [V] softmax(logits) */
   float* stats;          /* [4] u = 1 - max p (utils.py:127-130); sum p log(p+1e-12) (utils.py:133-137);

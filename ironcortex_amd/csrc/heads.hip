@@ -220,7 +220,13 @@ __device__ __forceinline__ void token_rows(const ic_heads_args& a, int lane, int
     x = a.H + (size_t)a.motor_idx * d; y = a.z;
   } else {
     const int r = grp - 1;
-    if (r == a.motor_idx || !a.mask[r]) return;
+    if (r == a.motor_idx || !a.mask[r]) {
+      // not part of the mean (model.py:314-317): zeros, so the combine can add all R rows
+      // without a mask test in its load chain (x + 0 is exact)
+      const int v = blockIdx.x * 256 + threadIdx.x;
+      if (v < a.V) a.per_region[(size_t)r * a.V + v] = 0.f;
+      return;
+    }
     rows = a.V;
     W = a.rh_W + (size_t)r * a.V * d; b = a.rh_b + (size_t)r * a.V; x = a.H + (size_t)r * d;
     y = a.per_region + (size_t)r * a.V;
@@ -257,7 +263,7 @@ __device__ __forceinline__ void token_rows(const ic_heads_args& a, int lane, int
 __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* red) {
   constexpr int VPT = 4;  // V <= 1024 (checked on the host)
   const int V = a.V, Kf = a.Kf, R = a.R, tid = threadIdx.x;
-  // issue every independent global read first: one round trip instead of a chain of them
+  // every global read is unconditional and independent of the others: one round trip
   constexpr int KF = 16;  // Kf <= 16 (checked on the host); fixed trip counts keep zg in registers
   float zg[KF];
 #pragma unroll
@@ -266,13 +272,11 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
   for (int r = 0; r < R; ++r) nw += (r != a.motor_idx && a.mask[r]) ? 1.0f : 0.0f;
   const int n = R * a.d;
   float g1 = 0.f, g0 = 0.f, sp = 0.f;
-  for (int i = tid; i < n; i += 256) {  // goodness(H) - goodness(H_par)   (utils.py:159-162)
-    const float h1 = a.H[i], h0 = a.H_par[i];
-    g1 = fmaf(h1, h1, g1);
-    g0 = fmaf(h0, h0, g0);
+  for (int r = tid; r < R; r += 256) {  // row sums of squares from k_heads
+    g1 += a.gsq[r];
+    g0 += a.gsq[R + r];
+    if (a.surprise) sp += a.surprise[r];
   }
-  if (a.surprise)
-    for (int r = tid; r < R; r += 256) sp += a.surprise[r];
   float gmx = -INFINITY;
 #pragma unroll
   for (int f = 0; f < KF; ++f) gmx = fmaxf(gmx, zg[f]);
@@ -290,13 +294,21 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
     const int v = tid + 256 * j;
     lg[j] = -INFINITY;
     if (v < V) {
+      float zf[KF];
+#pragma unroll
+      for (int f = 0; f < KF; ++f) zf[f] = f < Kf ? a.z[Kf + f * V + v] : 0.f;
+      float reg = 0.f;
+      for (int r0 = 0; r0 < R; r0 += 8) {  // inactive rows hold zeros: no mask test in the load chain
+        float pr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pr[u] = r0 + u < R ? a.per_region[(size_t)(r0 + u) * V + v] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) reg += pr[u];
+      }
       float acc = 0.f;
 #pragma unroll
       for (int f = 0; f < KF; ++f)
-        if (f < Kf) acc += (zg[f] / gsum) * a.z[Kf + f * V + v];
-      float reg = 0.f;
-      for (int r = 0; r < R; ++r)
-        if (r != a.motor_idx && a.mask[r]) reg += a.per_region[(size_t)r * V + v];
+        if (f < Kf) acc += (zg[f] / gsum) * zf[f];
       lg[j] = (acc + reg) / denom;
       a.logits[v] = lg[j];
       mx = fmaxf(mx, lg[j]);
@@ -337,10 +349,26 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
 // (device-scope fence + ticket per workgroup) cost 190 us for this 3000-workgroup grid -- the
 // fences write back / invalidate the per-XCD L2s -- against ~6 us for a second launch.  So the
 // combine stays a launch of its own.
+// sum of squares of row r of H and of H_par (goodness terms, utils.py:159-162), wave per row
+template <int DCH>
+__device__ __forceinline__ void sq_rows(const ic_heads_args& a, int lane, int wave) {
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.R) return;
+  RowFrag<DCH> h1, h0;
+  load_row(h1, a.H + (size_t)r * a.d, a.d, lane);
+  load_row(h0, a.H_par + (size_t)r * a.d, a.d, lane);
+  const float s1 = wave_sum(dot_frag(h1, h1)), s0 = wave_sum(dot_frag(h0, h0));
+  if (lane == 0) {
+    a.gsq[r] = s1;
+    a.gsq[a.R + r] = s0;
+  }
+}
+
 template <int DCH>
 __global__ __launch_bounds__(256) void k_heads(ic_heads_args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.y == a.R + 1) ws_write_rows<DCH>(a, lane, wave);
+  else if ((int)blockIdx.y == a.R + 2) sq_rows<DCH>(a, lane, wave);
   else token_rows<DCH>(a, lane, wave);
 }
 
@@ -447,7 +475,7 @@ extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
   IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "ic_heads_fwd: d=%d unsupported", a->d);
   IC_REQUIRE(a->motor_idx >= 0 && a->motor_idx < a->R, "ic_heads_fwd: motor_idx=%d", a->motor_idx);
   IC_REQUIRE(a->H && a->H_par && a->mask && a->lm_gate_W && a->lm_gate_b && a->lm_W && a->lm_b && a->rh_W && a->rh_b && a->z &&
-                 a->per_region && a->logits && a->probs && a->stats,
+                 a->per_region && a->logits && a->probs && a->stats && a->gsq,
              "ic_heads_fwd: NULL pointer");
   IC_REQUIRE(a->n_slots == 0 || (a->slots_in && a->slots_out), "ic_heads_fwd: NULL workspace slots");
   hipStream_t st = (hipStream_t)stream;
@@ -457,7 +485,7 @@ extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
   int nx = ic_ceil_div(max_rows, 8);
   if (ic_ceil_div(a->n_slots, 4) > nx) nx = ic_ceil_div(a->n_slots, 4);
   IC_DISPATCH_DCH(a->d, {
-    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 2 + a->R), dim3(256), 0, st, *a));
+    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 3 + a->R), dim3(256), 0, st, *a));
   });
   IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(1), dim3(256), 0, st, *a));
   IC_LAUNCH_CHECK("ic_heads_fwd");

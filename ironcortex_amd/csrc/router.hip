@@ -119,8 +119,9 @@ __global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
 }
 
 // ---------------------------------------------------------------- precision: combine (wave per (s,dst))
+// d > 256: edges walked one at a time (the all-at-once variant below would spill).
 template <int DCH>
-__global__ __launch_bounds__(256) void k_router_combine(ic_router_args a) {
+__global__ __launch_bounds__(256) void k_router_combine_serial(ic_router_args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.S * a.R) return;
@@ -183,6 +184,87 @@ __global__ __launch_bounds__(256) void k_router_combine(ic_router_args a) {
     }
   } else if (lane == 0) {
     for (int e = e0; e < e1; ++e) a.wgt[(size_t)s * a.E + e] = 0.f;
+  }
+  store_row(acc, a.M + (size_t)row * d, d, lane);
+}
+
+// d <= 256: message, key and precision rows of every active incoming edge are requested together.
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_combine(ic_router_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  const int d = a.d, s = row / a.R, r = row % a.R;
+  const int e0 = a.dst_off[r], deg = a.dst_off[r + 1] - e0;  // <= 8, checked on the host
+  const float sqrt_d = sqrtf((float)d);
+  bool act[8];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    act[i] = i < deg && a.mask_prev[s * a.R + a.src[e0 + (i < deg ? i : 0)]] != 0;
+    any |= act[i];
+  }
+  RowFrag<DCH> acc;
+  zero_frag(acc);
+  if (any) {
+    RowFrag<DCH> hd, q, m[8], k[8], P[8];
+    load_row(hd, a.H + (size_t)row * d, d, lane);
+    load_row(q, a.q + (size_t)row * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (act[i]) {
+        const size_t eo = ((size_t)s * a.E + e0 + i) * d;
+        load_row(m[i], a.msg + eo, d, lane);
+        load_row(k[i], a.keyv + eo, d, lane);
+        load_row(P[i], a.raw_P + (size_t)a.widx[e0 + i] * d, d, lane);
+      }
+    }
+    float logw[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      logw[i] = -INFINITY;
+      if (act[i]) {
+        const float score = wave_sum(dot_frag(q, k[i])) / sqrt_d;  // gate.py:308
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          const int c = 4 * lane + 256 * j;
+          if (c < d) {
+            float t;
+            t = m[i].v[j].x - hd.v[j].x; part += (t * t) * ic_softplus(P[i].v[j].x);
+            t = m[i].v[j].y - hd.v[j].y; part += (t * t) * ic_softplus(P[i].v[j].y);
+            t = m[i].v[j].z - hd.v[j].z; part += (t * t) * ic_softplus(P[i].v[j].z);
+            t = m[i].v[j].w - hd.v[j].w; part += (t * t) * ic_softplus(P[i].v[j].w);
+          }
+        }
+        const float mah = fminf(wave_sum(part), IC_MAX_EXP / 0.5f);  // gate.py:310
+        logw[i] = score - 0.5f * mah;
+        mx = fmaxf(mx, logw[i]);
+      }
+    }
+    float esum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (act[i]) esum += expf(logw[i] - mx);
+    const float logZ = mx + logf(fmaxf(esum, IC_EPS_DIV));  // gate.py:316
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < deg) {
+        float w = 0.f;
+        if (act[i]) {
+          w = expf(logw[i] - logZ);
+#pragma unroll
+          for (int j = 0; j < DCH; ++j) {
+            acc.v[j].x += w * m[i].v[j].x; acc.v[j].y += w * m[i].v[j].y;
+            acc.v[j].z += w * m[i].v[j].z; acc.v[j].w += w * m[i].v[j].w;
+          }
+        }
+        if (lane == 0) a.wgt[(size_t)s * a.E + e0 + i] = w;
+      }
+    }
+  } else if (lane == 0) {
+    for (int i = 0; i < deg; ++i) a.wgt[(size_t)s * a.E + e0 + i] = 0.f;
   }
   store_row(acc, a.M + (size_t)row * d, d, lane);
 }
@@ -630,8 +712,11 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
   if (a->flags & IC_RF_PRECISION) {
     IC_DISPATCH_DCH(a->d, {
       IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R), dim3(256), 0, st, *a));
-      IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<DCH>, dim3(ic_ceil_div(a->S * a->R, 4)), dim3(256), 0, st, *a));
     });
+    const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
+    if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
+    else if (a->d <= 512) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<2>, gcomb, dim3(256), 0, st, *a));
+    else IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<4>, gcomb, dim3(256), 0, st, *a));
   } else {
     // stream batch: 1 for a single stream (no extra registers), else 8 (4 at d > 512)
     if (a->S == 1) IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<DCH, 1>), dim3(nsl, a->R), dim3(256), 0, st, *a)); });

@@ -388,11 +388,11 @@ class LoopEngine:
         nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
         has, vers, bbufs = [], [], []
         for _b in range(nb):
-            bb = dict(z=z(Kf + Kf * V), per_region=z(R, V), probs=z(V), aux=z(4))
+            bb = dict(z=z(Kf + Kf * V), per_region=z(R, V), probs=z(V), aux=z(4), gsq=z(2 * R))
             ha = new("ic_heads_args", R=R, d=d, V=V, Kf=Kf, n_slots=m.work.slots.shape[0], motor_idx=m.io_idxs["motor"],
                      kwta_k=max(1, d // 4), lm_gate_W=m.lm_head.gate.weight, lm_gate_b=m.lm_head.gate.bias,
                      lm_W=hf.stacked("facet_W"), lm_b=hf.stacked("facet_b"), rh_W=hf.stacked("rh_W"),
-                     rh_b=hf.stacked("rh_b"), z=bb["z"], per_region=bb["per_region"], probs=bb["probs"])
+                     rh_b=hf.stacked("rh_b"), z=bb["z"], per_region=bb["per_region"], probs=bb["probs"], gsq=bb["gsq"])
             ver = None
             if m.verify is not None:
                 ver = (G * 3)()
