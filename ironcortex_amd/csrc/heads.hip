@@ -77,6 +77,65 @@ __global__ __launch_bounds__(256) void k_gemv(ic_gemv_desc g, const float* stats
   }
 }
 
+// Register variant for inputs of up to 64*NX columns: every wave loads the input vector itself
+// (lane-strided, L2 hits) TOGETHER with its two weight rows, and computes the LayerNorm
+// statistics itself -- no LDS staging, no workgroup barrier, one memory round trip.
+template <int NX>
+__global__ __launch_bounds__(256) void k_gemv_reg(ic_gemv_desc g, const float* stats, float* score) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cols = g.n0 + g.n1 + g.n2;
+  const int row0 = blockIdx.x * 8 + wave * 2;
+  if (row0 >= g.rows) return;
+  const bool two = row0 + 1 < g.rows;
+  float xr[NX], w0[NX], w1[NX], lg[NX], lb[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int c = lane + 64 * i;
+    float v = 0.f;
+    if (c < cols) {
+      if (c < g.n0) v = g.x0[c];
+      else if (c < g.n0 + g.n1) v = g.x1[c - g.n0];
+      else v = g.x2[c - g.n0 - g.n1];
+    }
+    xr[i] = v;
+    w0[i] = c < cols ? g.W[(size_t)row0 * cols + c] : 0.f;
+    w1[i] = (two && c < cols) ? g.W[(size_t)(row0 + 1) * cols + c] : 0.f;
+    lg[i] = (g.ln_g && c < cols) ? g.ln_g[c] : 0.f;
+    lb[i] = (g.ln_g && c < cols) ? g.ln_b[c] : 0.f;
+  }
+  const float b0 = g.b ? g.b[row0] : 0.f, b1 = (g.b && two) ? g.b[row0 + 1] : 0.f;
+  if (g.ln_g) {  // torch.nn.LayerNorm: biased variance
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) sm += xr[i];
+    const float mean = wave_sum(sm) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const float t = (lane + 64 * i < cols) ? xr[i] - mean : 0.f;
+      q += t * t;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + g.ln_eps);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xr[i] = (lane + 64 * i < cols) ? (xr[i] - mean) * rstd * lg[i] + lb[i] : 0.f;
+  }
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    a0 = fmaf(w0[i], xr[i], a0);
+    a1 = fmaf(w1[i], xr[i], a1);
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if (lane == 0) {
+    const float o0 = apply_act(a0 + b0, g.act);
+    g.y[row0] = o0;
+    if (two) g.y[row0 + 1] = apply_act(a1 + b1, g.act);
+    // the verifier's last layer: energy -> branch score (model.py:431-438)
+    if (score && row0 == 0) score[0] = 0.6f * stats[2] + 0.2f * (-o0) + 0.2f * stats[1];
+  }
+}
+
 // A whole chain of small GEMVs in ONE workgroup (16 waves): layer i+1 reads layer i's output
 // after a workgroup barrier, so a 3-6 layer MLP costs one launch instead of one per layer.
 // At <= a few MB of (cache-resident) weights the launch gaps dominate, not the single CU's
@@ -445,7 +504,12 @@ static int run_chain(const ic_gemv_desc* descs, int n, const float* stats, float
   }
   for (int i = 0; i < n; ++i) {
     float* sc = (i == n - 1) ? score : nullptr;
-    IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv, dim3(ic_ceil_div(descs[i].rows, 8)), dim3(256), 0, st, descs[i], stats, sc));
+    const int cols = descs[i].n0 + descs[i].n1 + descs[i].n2;
+    const dim3 grid(ic_ceil_div(descs[i].rows, 8)), blk(256);
+    if (cols <= 256) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<4>, grid, blk, 0, st, descs[i], stats, sc));
+    else if (cols <= 512) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<8>, grid, blk, 0, st, descs[i], stats, sc));
+    else if (cols <= 1024) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<16>, grid, blk, 0, st, descs[i], stats, sc));
+    else IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv, grid, blk, 0, st, descs[i], stats, sc));
   }
   return IC_OK;
 }
