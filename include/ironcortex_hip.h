@@ -187,6 +187,8 @@ typedef struct ic_router_args {
   float* keyv; /* [S,E,d] key vectors */
   float* q;    /* [S,R,d] queries */
   float* wgt;  /* [S,E]  routing weights (0 for inactive edges) */
+  int64_t H_sstride;    /* elements between consecutive streams' H blocks; 0 = contiguous (R*d) */
+  int64_t mask_sstride; /* bytes between consecutive streams' mask_prev rows; 0 = contiguous (R) */
 } ic_router_args;
 int ic_router_fwd(const ic_router_args* a, ic_stream_t stream);
 
@@ -244,6 +246,9 @@ typedef struct ic_gate_args {
   const int32_t* nbr;      /* [nnz] */
   float* scores;           /* [S,R] out */
   uint8_t* mask;           /* [S,R] out */
+  int64_t H_sstride;       /* elements between the H blocks of consecutive streams; 0 = contiguous (R*d).
+                              Lets the branches of one outer iteration, whose input states sit in
+                              arbitrary step slots, go through ONE launch. */
 } ic_gate_args;
 int ic_gate_scores(const ic_gate_args* a, ic_stream_t stream);
 /* Gate.select_k + nms_topk (gate.py:70-87, utils.py:107-124).  Total order: score
@@ -299,6 +304,8 @@ typedef struct ic_gemv_desc {
   int32_t n0, n1, n2;
   int32_t rows, act; /* IC_ACT_* */
   float ln_eps;
+  int32_t nbatch;    /* 0 or 1 = one vector; else that many independent input vectors ... */
+  int64_t x0_bs, x1_bs, x2_bs, y_bs; /* ... whose segments / outputs are this many floats apart */
 } ic_gemv_desc;
 /* descs is a HOST array; the n GEMVs run in order on the stream (each may read the previous y). */
 int ic_gemv_chain(const ic_gemv_desc* descs, int32_t n, ic_stream_t stream);
@@ -329,6 +336,13 @@ typedef struct ic_heads_args {
   float* stats;          /* [4] u = 1 - max p (utils.py:127-130); sum p log(p+1e-12) (utils.py:133-137);
                                 goodness(H) - goodness(H_par) (model.py:430); mean surprise */
   float* aux_surprise;   /* where the verifier's aux vector wants mean surprise, or NULL */
+  /* S > 1: the same for S steps at once (the branches of an outer iteration).  Per-stream blocks
+   * are contiguous (H [S,R,d], mask [S,R], slots_out, logits, surprise, z, per_region, gsq, probs;
+   * stats 4 floats apart, aux_surprise 4 floats apart) except the two inputs that come from the
+   * steps' parents, which have their own stream strides (0 = contiguous). */
+  int32_t S;                /* 0 or 1 = one step */
+  int64_t Hpar_sstride;     /* elements between consecutive streams' H_par blocks */
+  int64_t slots_in_sstride; /* elements between consecutive streams' slots_in blocks */
 } ic_heads_args;
 int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
 
@@ -336,6 +350,7 @@ int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
  * score below, in the same launch when the chain is small. */
 int ic_verify_score(const ic_gemv_desc* descs, int32_t n, const float* stats, float* score,
                     ic_stream_t stream);
+/* (batched descriptors: batch b reads stats + 4*b and writes score + b) */
 /* score = 0.6*stats[2] + 0.2*(-energy) + 0.2*stats[1]   (model.py:431-438) */
 int ic_branch_score(const float* stats, const float* energy, float* score, ic_stream_t stream);
 

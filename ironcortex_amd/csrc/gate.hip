@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_gate_scores(ic_gate_args a) {
   if (row >= a.S * a.R) return;
   const int s = row / a.R, r = row % a.R;
   RowFrag<DCH> h;
-  load_row(h, a.H + (size_t)row * a.d, a.d, lane);
+  load_row(h, a.H + (size_t)s * (a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d) + (size_t)r * a.d, a.d, lane);
   float part = 0.f;
 #pragma unroll
   for (int j = 0; j < DCH; ++j)
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_gate_fused(ic_gate_args a) {
   for (int r = wave; r < a.R; r += 4) {
     const int row = s * a.R + r;
     RowFrag<DCH> h;
-    load_row(h, a.H + (size_t)row * a.d, a.d, lane);
+    load_row(h, a.H + (size_t)s * (a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d) + (size_t)r * a.d, a.d, lane);
     float part = 0.f;
 #pragma unroll
     for (int j = 0; j < DCH; ++j)

@@ -33,9 +33,24 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+// Descriptor of batch b of a batched GEMV (ic_gemv_desc.nbatch > 1).
+__device__ __forceinline__ ic_gemv_desc gemv_batch(ic_gemv_desc g, int b) {
+  if (b == 0) return g;
+  if (g.x0) g.x0 += (int64_t)b * g.x0_bs;
+  if (g.x1) g.x1 += (int64_t)b * g.x1_bs;
+  if (g.x2) g.x2 += (int64_t)b * g.x2_bs;
+  g.y += (int64_t)b * g.y_bs;
+  return g;
+}
+
 // One wave per output row, 8 rows per workgroup; the input vector is staged (and optionally
 // layer-normalised) in LDS once per workgroup.
-__global__ __launch_bounds__(256) void k_gemv(ic_gemv_desc g, const float* stats, float* score) {
+__global__ __launch_bounds__(256) void k_gemv(ic_gemv_desc g0, const float* stats, float* score) {
+  const ic_gemv_desc g = gemv_batch(g0, blockIdx.y);
+  if (score) {
+    stats += 4 * blockIdx.y;
+    score += blockIdx.y;
+  }
   __shared__ float xs[kMaxCols];
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -81,7 +96,12 @@ __global__ __launch_bounds__(256) void k_gemv(ic_gemv_desc g, const float* stats
 // (lane-strided, L2 hits) TOGETHER with its two weight rows, and computes the LayerNorm
 // statistics itself -- no LDS staging, no workgroup barrier, one memory round trip.
 template <int NX>
-__global__ __launch_bounds__(256) void k_gemv_reg(ic_gemv_desc g, const float* stats, float* score) {
+__global__ __launch_bounds__(256) void k_gemv_reg(ic_gemv_desc g0, const float* stats, float* score) {
+  const ic_gemv_desc g = gemv_batch(g0, blockIdx.y);
+  if (score) {
+    stats += 4 * blockIdx.y;
+    score += blockIdx.y;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cols = g.n0 + g.n1 + g.n2;
   const int row0 = blockIdx.x * 8 + wave * 2;
@@ -423,17 +443,39 @@ __device__ __forceinline__ void sq_rows(const ic_heads_args& a, int lane, int wa
   }
 }
 
+// Arguments of stream s of a batched call (ic_heads_args.S > 1): every pointer moved to that
+// stream's block.
+__device__ __forceinline__ ic_heads_args heads_stream(ic_heads_args a, int s) {
+  if (s == 0) return a;
+  const size_t rd = (size_t)a.R * a.d, sd = (size_t)a.n_slots * a.d;
+  a.H += s * rd;
+  a.mask += (size_t)s * a.R;
+  a.H_par += (int64_t)s * (a.Hpar_sstride ? a.Hpar_sstride : (int64_t)rd);
+  if (a.slots_in) a.slots_in += (int64_t)s * (a.slots_in_sstride ? a.slots_in_sstride : (int64_t)sd);
+  if (a.slots_out) a.slots_out += s * sd;
+  if (a.surprise) a.surprise += (size_t)s * a.R;
+  a.z += (size_t)s * (a.Kf + a.Kf * a.V);
+  a.per_region += (size_t)s * a.R * a.V;
+  a.gsq += (size_t)s * 2 * a.R;
+  a.logits += (size_t)s * a.V;
+  a.probs += (size_t)s * a.V;
+  a.stats += 4 * s;
+  if (a.aux_surprise) a.aux_surprise += 4 * s;
+  return a;
+}
+
 template <int DCH>
-__global__ __launch_bounds__(256) void k_heads(ic_heads_args a) {
+__global__ __launch_bounds__(256) void k_heads(ic_heads_args a0) {
+  const ic_heads_args a = heads_stream(a0, blockIdx.z);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.y == a.R + 1) ws_write_rows<DCH>(a, lane, wave);
   else if ((int)blockIdx.y == a.R + 2) sq_rows<DCH>(a, lane, wave);
   else token_rows<DCH>(a, lane, wave);
 }
 
-__global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a) {
+__global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a0) {
   __shared__ float red[4];
-  logits_combine(a, red);
+  logits_combine(heads_stream(a0, blockIdx.x), red);
 }
 
 __global__ void k_branch_score(const float* stats, const float* energy, float* score) {
@@ -493,7 +535,9 @@ static int run_chain(const ic_gemv_desc* descs, int n, const float* stats, float
     if (rc) return rc;
     bytes += (size_t)descs[i].rows * (descs[i].n0 + descs[i].n1 + descs[i].n2) * 4;
   }
-  if (n >= 1 && n <= 6 && bytes <= (128u << 10)) {
+  bool batched = false;
+  for (int i = 0; i < n; ++i) batched |= descs[i].nbatch > 1;
+  if (n >= 1 && n <= 6 && bytes <= (128u << 10) && !batched) {
     ChainArgs c;
     for (int i = 0; i < n; ++i) c.d[i] = descs[i];
     c.n = n;
@@ -505,7 +549,7 @@ static int run_chain(const ic_gemv_desc* descs, int n, const float* stats, float
   for (int i = 0; i < n; ++i) {
     float* sc = (i == n - 1) ? score : nullptr;
     const int cols = descs[i].n0 + descs[i].n1 + descs[i].n2;
-    const dim3 grid(ic_ceil_div(descs[i].rows, 8)), blk(256);
+    const dim3 grid(ic_ceil_div(descs[i].rows, 8), descs[i].nbatch > 1 ? descs[i].nbatch : 1), blk(256);
     if (cols <= 256) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<4>, grid, blk, 0, st, descs[i], stats, sc));
     else if (cols <= 512) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<8>, grid, blk, 0, st, descs[i], stats, sc));
     else if (cols <= 1024) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<16>, grid, blk, 0, st, descs[i], stats, sc));
@@ -544,14 +588,16 @@ extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
   IC_REQUIRE(a->n_slots == 0 || (a->slots_in && a->slots_out), "ic_heads_fwd: NULL workspace slots");
   hipStream_t st = (hipStream_t)stream;
   IC_REQUIRE(a->V <= 1024, "ic_heads_fwd: V=%d (need <= 1024)", a->V);
+  const int S = a->S > 1 ? a->S : 1;
+  IC_REQUIRE(S <= 64, "ic_heads_fwd: S=%d (need <= 64)", S);
   const int lm_rows = a->Kf + a->Kf * a->V;
   const int max_rows = lm_rows > a->V ? lm_rows : a->V;
   int nx = ic_ceil_div(max_rows, 8);
   if (ic_ceil_div(a->n_slots, 4) > nx) nx = ic_ceil_div(a->n_slots, 4);
   IC_DISPATCH_DCH(a->d, {
-    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 3 + a->R), dim3(256), 0, st, *a));
+    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 3 + a->R, S), dim3(256), 0, st, *a));
   });
-  IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(1), dim3(256), 0, st, *a));
+  IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(S), dim3(256), 0, st, *a));
   IC_LAUNCH_CHECK("ic_heads_fwd");
   return IC_OK;
 }

@@ -11,6 +11,17 @@ namespace {
 
 constexpr int kRowsPerBlock = 8;
 
+// Row r of stream s of the input states / previous mask; streams may be strided (the branches of
+// one outer iteration read their inputs from arbitrary step slots).
+__device__ __forceinline__ const float* h_row(const ic_router_args& a, int s, int r) {
+  const int64_t hs = a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d;
+  return a.H + (int64_t)s * hs + (size_t)r * a.d;
+}
+__device__ __forceinline__ bool prev_on(const ic_router_args& a, int s, int r) {
+  const int64_t ms = a.mask_sstride ? a.mask_sstride : (int64_t)a.R;
+  return a.mask_prev[(int64_t)s * ms + r] != 0;
+}
+
 // ---------------------------------------------------------------- default forward
 // Workgroup = (8-row slice, destination r); incoming edges are walked in index order (the
 // reference's index_add_ order).  Streams are served SB at a time: an edge's two weight rows are
@@ -37,7 +48,7 @@ __global__ __launch_bounds__(256) void k_router_fwd(ic_router_args a) {
       unsigned m = 0;
 #pragma unroll
       for (int i = 0; i < SB; ++i)
-        if (s0 + i < a.S && a.mask_prev[(s0 + i) * a.R + src]) m |= 1u << i;
+        if (s0 + i < a.S && prev_on(a, s0 + i, src)) m |= 1u << i;
       if (!m) continue;
       const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
       RowFrag<DCH> w0, w1, h[SB];
@@ -46,7 +57,7 @@ __global__ __launch_bounds__(256) void k_router_fwd(ic_router_args a) {
       const float bias = a.ebias[e];
 #pragma unroll
       for (int i = 0; i < SB; ++i)
-        if ((m >> i) & 1u) load_row(h[i], a.H + ((size_t)(s0 + i) * a.R + src) * d, d, lane);
+        if ((m >> i) & 1u) load_row(h[i], h_row(a, s0 + i, src), d, lane);
 #pragma unroll
       for (int i = 0; i < SB; ++i) {
         if ((m >> i) & 1u) {
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
   if (y < a.E) {
     const int e = y, src = a.src[e];
     bool any = false;
-    for (int s = 0; s < a.S; ++s) any |= a.mask_prev[s * a.R + src] != 0;
+    for (int s = 0; s < a.S; ++s) any |= prev_on(a, s, src);
     if (!any) return;
     const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
     const float* K = a.key_W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
@@ -86,8 +97,8 @@ __global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
     load_row(k1, K + d, d, lane);
     const float bias = a.ebias[e];
     for (int s = 0; s < a.S; ++s) {
-      if (!a.mask_prev[s * a.R + src]) continue;
-      load_row(h, a.H + ((size_t)s * a.R + src) * d, d, lane);
+      if (!prev_on(a, s, src)) continue;
+      load_row(h, h_row(a, s, src), d, lane);
       const float m0 = wave_sum(dot_frag(w0, h)), m1 = wave_sum(dot_frag(w1, h));
       const float q0 = wave_sum(dot_frag(k0, h)), q1 = wave_sum(dot_frag(k1, h));
       if (lane < 2) {
@@ -104,14 +115,14 @@ __global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
     bool loaded = false;
     for (int s = 0; s < a.S; ++s) {
       bool any = false;
-      for (int e = e0; e < e1; ++e) any |= a.mask_prev[s * a.R + a.src[e]] != 0;
+      for (int e = e0; e < e1; ++e) any |= prev_on(a, s, a.src[e]);
       if (!any) continue;
       if (!loaded) {
         load_row(q0, Q, d, lane);
         load_row(q1, Q + d, d, lane);
         loaded = true;
       }
-      load_row(h, a.H + ((size_t)s * a.R + r) * d, d, lane);
+      load_row(h, h_row(a, s, r), d, lane);
       const float v0 = wave_sum(dot_frag(q0, h)), v1 = wave_sum(dot_frag(q1, h));
       if (lane < 2) a.q[((size_t)s * a.R + r) * d + row0 + lane] = lane ? v1 : v0;
     }
@@ -136,9 +147,9 @@ __global__ __launch_bounds__(256) void k_router_combine_serial(ic_router_args a)
   for (int e = e0; e < e1; ++e) {
     const int i = e - e0;
     logw[i] = -INFINITY;
-    if (!a.mask_prev[s * a.R + a.src[e]]) continue;
+    if (!prev_on(a, s, a.src[e])) continue;
     if (!any) {
-      load_row(hd, a.H + (size_t)row * d, d, lane);
+      load_row(hd, h_row(a, s, r), d, lane);
       load_row(q, a.q + (size_t)row * d, d, lane);
       any = true;
     }
@@ -201,14 +212,14 @@ __global__ __launch_bounds__(256) void k_router_combine(ic_router_args a) {
   bool any = false;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    act[i] = i < deg && a.mask_prev[s * a.R + a.src[e0 + (i < deg ? i : 0)]] != 0;
+    act[i] = i < deg && prev_on(a, s, a.src[e0 + (i < deg ? i : 0)]);
     any |= act[i];
   }
   RowFrag<DCH> acc;
   zero_frag(acc);
   if (any) {
     RowFrag<DCH> hd, q, m[8], k[8], P[8];
-    load_row(hd, a.H + (size_t)row * d, d, lane);
+    load_row(hd, h_row(a, s, r), d, lane);
     load_row(q, a.q + (size_t)row * d, d, lane);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -284,11 +295,11 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_ar
   const bool prec = a.flags & IC_RF_PRECISION;
   RowFrag<DCH> G, t;
   load_row(G, b.gM + (size_t)row * d, d, lane);
-  load_row(t, a.H + (size_t)row * d, d, lane);
+  load_row(t, h_row(a, s, r), d, lane);
   store_row(t, b.tape_H + (size_t)row * d, d, lane);
   bool any = false;
   for (int e = e0; e < e1; ++e) {
-    const bool act = a.mask_prev[s * a.R + a.src[e]] != 0;
+    const bool act = prev_on(a, s, a.src[e]);
     any |= act;
     if (lane == 0) b.tape_eact[(size_t)s * a.E + e] = act ? 1 : 0;
     if (act && !prec) store_row(G, b.tape_gmsg + ((size_t)s * a.E + e) * d, d, lane);
@@ -308,14 +319,14 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_ar
       const int i = e - e0;
       gw[i] = 0.f;
       const float w = a.wgt[(size_t)s * a.E + e];
-      if (!a.mask_prev[s * a.R + a.src[e]]) continue;
+      if (!prev_on(a, s, a.src[e])) continue;
       load_row(m, a.msg + ((size_t)s * a.E + e) * d, d, lane);
       gw[i] = wave_sum(dot_frag(G, m));
       inner += w * gw[i];
     }
     for (int e = e0; e < e1; ++e) {
       const int i = e - e0;
-      if (!a.mask_prev[s * a.R + a.src[e]]) continue;
+      if (!prev_on(a, s, a.src[e])) continue;
       const size_t eo = ((size_t)s * a.E + e) * d;
       const float w = a.wgt[(size_t)s * a.E + e];
       const float g_lw = w * (gw[i] - inner);
@@ -376,13 +387,13 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
   const bool prec = a.flags & IC_RF_PRECISION;
   RowFrag<DCH> G, t;
   load_row(G, b.gM + (size_t)row * d, d, lane);
-  load_row(t, a.H + (size_t)row * d, d, lane);
+  load_row(t, h_row(a, s, r), d, lane);
   // activity of the incoming edges: wave-uniform loads, all requested together
   bool act[8];
   bool any = false;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    act[i] = i < deg && a.mask_prev[s * a.R + a.src[e0 + (i < deg ? i : 0)]] != 0;
+    act[i] = i < deg && prev_on(a, s, a.src[e0 + (i < deg ? i : 0)]);
     any |= act[i];
   }
   store_row(t, b.tape_H + (size_t)row * d, d, lane);
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   // block-uniform activity test
   bool any = false;
   for (int s = 0; s < a.S; ++s)
-    any |= is_q ? (b.tape_qact[s * a.R + r] != 0) : (a.mask_prev[s * a.R + src] != 0);
+    any |= is_q ? (b.tape_qact[s * a.R + r] != 0) : (prev_on(a, s, src));
   if (!any) return;
   const float* W = is_q ? a.query_W + (size_t)r * dd : a.W + (size_t)a.widx[e] * dd;
   const float* K = (!is_q && prec) ? a.key_W + (size_t)a.widx[e] * dd : nullptr;
@@ -511,14 +522,14 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   const float bias = is_q ? 1.0f : a.ebias[e];
   const int SE = a.S * a.E, SR = a.S * a.R;
   for (int s = 0; s < a.S; ++s) {
-    const bool act = is_q ? (b.tape_qact[s * a.R + r] != 0) : (a.mask_prev[s * a.R + src] != 0);
+    const bool act = is_q ? (b.tape_qact[s * a.R + r] != 0) : (prev_on(a, s, src));
     if (!act) continue;  // block-uniform
     RowFrag<DCH> h, acc;
     zero_frag(acc);
     float part_b = 0.f;
     float* gvec = is_q ? b.tape_gq + ((size_t)s * a.R + r) * d : b.tape_gmsg + ((size_t)s * a.E + e) * d;
     const float* gkey = K ? b.tape_gkey + ((size_t)s * a.E + e) * d : nullptr;
-    if (!is_q) load_row(h, a.H + ((size_t)s * a.R + src) * d, d, lane);
+    if (!is_q) load_row(h, h_row(a, s, src), d, lane);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int ch = row0 + i;
@@ -583,7 +594,7 @@ __global__ __launch_bounds__(256) void k_router_gather_bwd(ic_router_bwd_args b,
     load_row(g, b.gHd + (size_t)row * d, d, lane);
     if (b.tape_qact[row]) sum_slabs(g, b.slab_q + (size_t)row * d, (size_t)SR * d, nslab, d, lane);
   }
-  if (a.mask_prev[row]) {
+  if (prev_on(a, s, r)) {
     for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
       const int e = b.src_edges[i];
       sum_slabs(g, b.slab + ((size_t)s * a.E + e) * d, (size_t)SE * d, nslab, d, lane);

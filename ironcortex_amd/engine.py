@@ -80,11 +80,6 @@ class LoopEngine:
     def __init__(self, model):
         self.model = model
         self.enabled = True
-        # Side stream for the branch-parallel part of an outer iteration (gate/router of the later
-        # branches, heads/verifier of the earlier ones).  Off: measured on MI355X it LOSES 3 ms per
-        # train_step (loop forward 26.8 -> 30.0 ms) -- the three cross-stream event waits per
-        # iteration cost more than the ~9 launches they take off the critical path.
-        self.two_streams = False
         self._arena: Optional[StepArena] = None
         self._arena_key = None
         self._ws = None
@@ -202,10 +197,13 @@ class LoopEngine:
         rP, bP = router._params(), bank.params()
         kw_k, kw_soft, kw_temp = bank.kwta_now()
         flags = bank._flags(kw_soft, bank.cells[0].disable_kwta, True)
+        # the branches of an outer iteration go through gate / router / heads as ONE launch each
+        # (streams of the same call), so the loop's inputs are kept once per branch
+        nbr_ = 1 if cfg.train_deterministic_inner_loop else max(1, cfg.B_br)
         focus_any = (focus_map.any().to(_U8).reshape(1) if focus_map.numel() > 0
-                     else torch.ones(1, dtype=_U8, device=dev))
-        H0 = H_prev.detach().contiguous().float()
-        mask0 = reg_mask_prev.to(_U8).contiguous()
+                     else torch.ones(1, dtype=_U8, device=dev)).repeat(nbr_)
+        H0 = H_prev.detach().float().reshape(1, R, d).repeat(nbr_, 1, 1)
+        mask0 = reg_mask_prev.to(_U8).reshape(1, R).repeat(nbr_, 1)
         off, nbr = gate._tables(dev)
 
         # ---- structs: everything static is set once per loop
@@ -244,34 +242,58 @@ class LoopEngine:
         denom = float(max(1, cfg.K_inner - 1))
         parent: List[int] = []
         step_pos_l: List[float] = []
+        H0p, mask0p = H0.data_ptr(), mask0.data_ptr()
 
-        def front(par: int, step_k: int, u_mean: float, burst: int, stream) -> int:
-            """Gate + router of a new inner step whose H input is the output of step `par` (-1: the
-            loop's H_prev), on `stream`.  Returns the step id; region(id) must follow."""
+        def in_ptrs(par: int, b: int):
+            """(H, mask) device addresses of the input of a step: slot of step `par`, or copy b of
+            the loop's own H_prev / reg_mask_prev."""
+            if par < 0:
+                return H0p + b * R * d * 4, mask0p + b * R
+            return CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
+
+        def front(pars: List[int], step_k: int, u_mean: float, burst: int, stream) -> List[int]:
+            """Gate + router of len(pars) new inner steps (consecutive slots) whose H inputs are the
+            outputs of steps pars[b] (-1: the loop's H_prev), as ONE launch sequence with one
+            stream per step.  Returns the step ids; region(id) must follow in order."""
+            nb = len(pars)
             i = len(parent)
             a = i0 + i
-            if par < 0:
-                h_in, mk_in = H0.data_ptr(), mask0.data_ptr()
-            else:
-                h_in, mk_in = CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
-            ga.H, ga.t5, ga.t6 = h_in, w5 * float(gate.value_bias), w6 * float(u_mean)
+            h_in, mk_in = in_ptrs(pars[0], 0)
+            hs = ms = 0
+            if nb > 1:
+                h1, m1 = in_ptrs(pars[1], 1)
+                hs, ms = (h1 - h_in) // 4, m1 - mk_in
+                for b in range(2, nb):  # equally spaced inputs only (always true for two branches)
+                    hb, mb = in_ptrs(pars[b], b)
+                    if (hb - h_in) // 4 != b * hs or mb - mk_in != b * ms:
+                        return [j for b2 in range(nb) for j in front([pars[b2]], step_k, u_mean, burst, stream)]
+                if hs == R * d:
+                    hs = 0
+                if ms == R:
+                    ms = 0
+                if (hs == 0 and h1 - h_in != R * d * 4) or (ms == 0 and m1 - mk_in != R):
+                    return [j for b2 in range(nb) for j in front([pars[b2]], step_k, u_mean, burst, stream)]
+            ga.S, ga.H, ga.H_sstride = nb, h_in, hs
+            ga.t5, ga.t6 = w5 * float(gate.value_bias), w6 * float(u_mean)
             ga.k_total = max(0, cfg.k_active + burst)
             ga.scores, ga.mask = CP["scores"] + a * CS["scores"], CP["mask"] + a * CS["mask"]
             rc = g_fwd(ga_ref, stream)
             if rc:
                 check(rc, "ic_gate")
             if E > 0:
-                ra.H, ra.mask_prev, ra.M = h_in, mk_in, CP["M"] + a * CS["M"]
+                ra.S, ra.H, ra.mask_prev, ra.M = nb, h_in, mk_in, CP["M"] + a * CS["M"]
+                ra.H_sstride, ra.mask_sstride = hs, ms
                 for k in rsaved:
                     setattr(ra, k, CP[k] + a * CS[k])
                 rc = r_fwd(ra_ref, stream)
                 if rc:
                     check(rc, "ic_router_fwd")
             # (E == 0: M stays at the zeros the arena was created with)
-            parent.append(par)
-            step_pos_l.append(float(step_k) / denom)
-            m.counters["inner_steps"] += 1
-            return i
+            for par in pars:
+                parent.append(par)
+                step_pos_l.append(float(step_k) / denom)
+            m.counters["inner_steps"] += nb
+            return list(range(i, i + nb))
 
         def region(i: int, stream) -> None:
             """Region phase of step i (state chained from the previously executed step)."""
@@ -292,18 +314,15 @@ class LoopEngine:
                 check(rc, "ic_region_phase_fwd")
 
         def step(par: int, step_k: int, u_mean: float, burst: int) -> int:
-            i = front(par, step_k, u_mean, burst, st)
+            (i,) = front([par], step_k, u_mean, burst, st)
             region(i, st)
             return i
 
         Hf, Mf = chunk.fields["H"], chunk.fields["mask"]
-        H_of = lambda i: Hf[i0 + i] if i >= 0 else H0
-        mask_of = lambda i: Mf[i0 + i] if i >= 0 else mask0
-        H0p, mask0p = H0.data_ptr(), mask0.data_ptr()
-        ptr_of = lambda i: ((CP["H"] + (i0 + i) * CS["H"], CP["mask"] + (i0 + i) * CS["mask"]) if i >= 0
-                            else (H0p, mask0p))
+        H_of = lambda i: Hf[i0 + i] if i >= 0 else H0[0]
+        mask_of = lambda i: Mf[i0 + i] if i >= 0 else mask0[0]
         with torch.no_grad():
-            best, last_step, traces = self._drive((step, front, region), ptr_of, H_of, K_inner, dev, chunk, i0, H0, mask0)
+            best, last_step, traces = self._drive((step, front, region), in_ptrs, H_of, K_inner, dev, chunk, i0)
         n = len(parent)
         last_logits = (chunk.fields["logits"][i0 + last_step].clone() if last_step >= 0
                        else torch.zeros(m.V, device=dev))
@@ -326,7 +345,7 @@ class LoopEngine:
                 router._last_wgt = f["wgt"][li:li + 1, :E]
             self._state_in_arena = True
         if m._units is not None and E > 0 and n > 0:
-            self._count_units(chunk, i0, parent, mask0)
+            self._count_units(chunk, i0, parent, mask0[0])
 
         reg_mask = mask_of(best).bool()
         if grad and n > 0:
@@ -363,13 +382,16 @@ class LoopEngine:
                      m.critic.mlp.net[0], m.critic.mlp.net[2]]
         if m.verify is not None:
             mods += [m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]]
-        key = (dev, hf.flat.data_ptr()) + tuple(p.data_ptr() for l in mods for p in (l.weight, l.bias))
+        nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
+        key = (dev, nb, hf.flat.data_ptr()) + tuple(p.data_ptr() for l in mods for p in (l.weight, l.bias))
         hs = getattr(self, "_hs", None)
         if hs is not None and hs["key"] == key:
             return hs
         R, d, V, Kf = m.R, m.d, m.V, m.lm_head.Kf
         z = lambda *s: torch.zeros(*s, device=dev)
-        buf = dict(ls=z(64), ws_prev=z(d), motor=z(d), p_h=z(d), p=z(d), g_h=z(2 * d), g=z(d), c_h=z(2 * d))
+        # per-branch scratch blocks are contiguous: branch b of a batched call uses block b
+        buf = dict(ls=z(64), ws_prev=z(d), motor=z(d), p_h=z(d), p=z(d), g_h=z(2 * d), g=z(d), c_h=z(2 * d),
+                   z=z(nb, Kf + Kf * V), per_region=z(nb, R, V), probs=z(nb, V), aux=z(nb, 4), gsq=z(nb, 2 * R))
         P = {k: t.data_ptr() for k, t in buf.items()}
         G = CLASSES["ic_gemv_desc"]
 
@@ -383,32 +405,25 @@ class LoopEngine:
                 g.ln_g, g.ln_b, g.ln_eps = ln.weight.data_ptr(), ln.bias.data_ptr(), ln.eps
             assert lin_.weight.shape[1] == sum(n for _, n in xs) and lin_.weight.is_contiguous()
 
-        # one set of head scratch + structs per branch: branch b's heads may run on the side stream
-        # while branch b+1's run on the main one
-        nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
-        has, vers, bbufs = [], [], []
-        for _b in range(nb):
-            bb = dict(z=z(Kf + Kf * V), per_region=z(R, V), probs=z(V), aux=z(4), gsq=z(2 * R))
-            ha = new("ic_heads_args", R=R, d=d, V=V, Kf=Kf, n_slots=m.work.slots.shape[0], motor_idx=m.io_idxs["motor"],
-                     kwta_k=max(1, d // 4), lm_gate_W=m.lm_head.gate.weight, lm_gate_b=m.lm_head.gate.bias,
-                     lm_W=hf.stacked("facet_W"), lm_b=hf.stacked("facet_b"), rh_W=hf.stacked("rh_W"),
-                     rh_b=hf.stacked("rh_b"), z=bb["z"], per_region=bb["per_region"], probs=bb["probs"], gsq=bb["gsq"])
-            ver = None
-            if m.verify is not None:
-                ver = (G * 3)()
-                silu = ENUMS["IC_ACT_SILU"]
-                ln, l1, l2, l3 = m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]
-                hid = l1.weight.shape[0]
-                bb["h1"], bb["h2"] = z(hid), z(hid)
-                desc(ver[0], l1, [(0, d), (bb["probs"].data_ptr(), V), (bb["aux"].data_ptr(), m.verify.aux_dim)],
-                     bb["h1"].data_ptr(), silu, ln)  # energy.py:17-30
-                desc(ver[1], l2, [(bb["h1"].data_ptr(), hid)], bb["h2"].data_ptr(), silu)
-                desc(ver[2], l3, [(bb["h2"].data_ptr(), hid)], 0, ENUMS["IC_ACT_NONE"])
-            has.append(ha); vers.append(ver); bbufs.append(bb)
-        buf.update({k: v for k, v in bbufs[0].items()})  # branch 0's scratch under the plain names
-        P.update({k: t.data_ptr() for k, t in bbufs[0].items()})
-        ha, ver = has[0], vers[0]
-
+        ha = new("ic_heads_args", R=R, d=d, V=V, Kf=Kf, n_slots=m.work.slots.shape[0], motor_idx=m.io_idxs["motor"],
+                 kwta_k=max(1, d // 4), lm_gate_W=m.lm_head.gate.weight, lm_gate_b=m.lm_head.gate.bias,
+                 lm_W=hf.stacked("facet_W"), lm_b=hf.stacked("facet_b"), rh_W=hf.stacked("rh_W"),
+                 rh_b=hf.stacked("rh_b"), z=buf["z"], per_region=buf["per_region"], probs=buf["probs"], gsq=buf["gsq"])
+        ver = None
+        if m.verify is not None:
+            ver = (G * 3)()
+            silu = ENUMS["IC_ACT_SILU"]
+            ln, l1, l2, l3 = m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]
+            hid = l1.weight.shape[0]
+            buf["h1"], buf["h2"] = z(nb, hid), z(nb, hid)
+            P["h1"], P["h2"] = buf["h1"].data_ptr(), buf["h2"].data_ptr()
+            desc(ver[0], l1, [(0, d), (P["probs"], V), (P["aux"], m.verify.aux_dim)], P["h1"], silu, ln)  # energy.py:17-30
+            desc(ver[1], l2, [(P["h1"], hid)], P["h2"], silu)
+            desc(ver[2], l3, [(P["h2"], hid)], 0, ENUMS["IC_ACT_NONE"])
+            # batch strides (floats) used when the branches' verifier chains run as one launch per layer
+            ver[0].x0_bs, ver[0].x1_bs, ver[0].x2_bs, ver[0].y_bs = R * d, V, 4, hid
+            ver[1].x0_bs, ver[1].y_bs = hid, hid
+            ver[2].x0_bs, ver[2].y_bs = hid, 1
         steer = None
         if m.plan is not None:
             steer = (G * 6)()
@@ -420,68 +435,77 @@ class LoopEngine:
             desc(steer[4], mods[5], [(P["ws_prev"], d), (P["g"], d)], P["c_h"], gelu)  # heads.py:69-70
             desc(steer[5], mods[6], [(P["c_h"], 2 * d)], P["ls"] + 40 * 4, none)
         sa = new("ic_steer_args", R=R, d=d, motor_idx=m.io_idxs["motor"], ws_prev=buf["ws_prev"], motor=buf["motor"])
-        side = torch.cuda.Stream(device=dev) if nb > 1 else None
-        ev = lambda n: [torch.cuda.Event() for _ in range(n)]
-        self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods, has=has, vers=vers,
-                        bbufs=bbufs, side=side, ev_front=ev(nb), ev_reg=ev(nb), ev_side=torch.cuda.Event())
+        self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods, nb=nb)
         return self._hs
 
-    def _drive(self, steps, ptr_of, H_of, K_inner, dev, chunk, i0, H0, mask0):
+    def _drive(self, steps, in_ptrs, H_of, K_inner, dev, chunk, i0):
         """The control flow of reference model.py:329-460 over step ids, heads on the HIP library.
-
-        Two streams: within an outer iteration the branches are chained only through the region
-        state, so the side stream runs gate + router of the later branches and heads + verifier
-        of the earlier ones while the main stream runs the region phases back to back."""
+        Within an outer iteration the branches are chained only through the region state: their
+        gate, router, heads and verifier run as one launch sequence with one stream per branch;
+        only the region phases run branch after branch."""
         step, front, region = steps
         m = self.model
         cfg, gate = m.cfg, m.gate
         L, st = lib(), stream_handle()
         keep = (lambda t: t) if (m._logits_detached and torch.is_grad_enabled()) else (lambda t: t.clone())
         hs = self._heads_setup(dev)
-        has, vers, bbufs = hs["has"], hs["vers"], hs["bbufs"]
-        steer, sa, P, ls = hs["steer"], hs["sa"], hs["P"], hs["buf"]["ls"]
-        sa_ref = ctypes.byref(sa)
-        d, motor = m.d, m.io_idxs["motor"]
+        ha, ver, steer, sa, P, ls, nb = hs["ha"], hs["ver"], hs["steer"], hs["sa"], hs["P"], hs["buf"]["ls"], hs["nb"]
+        ha_ref, sa_ref = ctypes.byref(ha), ctypes.byref(sa)
+        R, d, motor = m.R, m.d, m.io_idxs["motor"]
         CP, CS = chunk.ptr, chunk.stride
         afd = "surprise_o" in CP
-        aux_on = vers[0] is not None and m.verify.aux_dim > 0
+        aux_on = ver is not None and m.verify.aux_dim > 0
         if aux_on:  # model.py:396-404: [mixer energy, mean surprise (written per step), attention entropy]
             ent = getattr(m.local_mix.attn, "last_attn_entropy", None)
             a02 = torch.stack([m.local_mix.last_energy.detach().reshape(()),
                                (ent.detach().reshape(()).to(dev) if ent is not None else torch.zeros((), device=dev))])
-            for bb in bbufs:
-                bb["aux"][0::2] = a02
-        for ha, bb in zip(has, bbufs):
-            ha.aux_surprise = bb["aux"].data_ptr() + 4 if aux_on else None
-        slots0 = m.work.slots.detach().contiguous()
-        slots_ptr = lambda i: CP["slots"] + (i0 + i) * CS["slots"] if i >= 0 else slots0.data_ptr()
+            hs["buf"]["aux"][:, 0::2] = a02
+        ha.aux_surprise = P["aux"] + 4 if aux_on else None
+        n_slots = m.work.slots.shape[0]
+        slots0 = m.work.slots.detach().reshape(1, n_slots, d).repeat(nb, 1, 1)
+        s0p = slots0.data_ptr()
+        slots_ptr = lambda i, b: CP["slots"] + (i0 + i) * CS["slots"] if i >= 0 else s0p + b * n_slots * d * 4
         lsp = P["ls"]
         heads_fwd, chain, vscore, steer_sel = L.ic_heads_fwd, L.ic_gemv_chain, L.ic_verify_score, L.ic_steer_select
 
-        def heads(cur: int, par: int, slots_from: int, b: int, stream) -> None:
-            ha = has[b]
-            a = i0 + cur
+        def heads(ids: List[int], pars: List[int], slots_from: List[int]) -> bool:
+            """Workspace write + logits + statistics of the consecutive steps ids (one launch
+            sequence).  False when the parents' blocks are not equally spaced (then: one by one)."""
+            n = len(ids)
+            a = i0 + ids[0]
+            hp0, sp0 = in_ptrs(pars[0], 0)[0], slots_ptr(slots_from[0], 0)
+            hps = sps = 0
+            if n > 1:
+                hps, sps = (in_ptrs(pars[1], 1)[0] - hp0) // 4, (slots_ptr(slots_from[1], 1) - sp0) // 4
+                for b in range(2, n):
+                    if (in_ptrs(pars[b], b)[0] - hp0) // 4 != b * hps or (slots_ptr(slots_from[b], b) - sp0) // 4 != b * sps:
+                        return False
+                if hps == 0 or sps == 0:
+                    return False  # 0 means "contiguous" in the ABI
+            ha.S, ha.Hpar_sstride, ha.slots_in_sstride = n, hps, sps
             ha.H, ha.mask = CP["H"] + a * CS["H"], CP["mask"] + a * CS["mask"]
-            ha.H_par = ptr_of(par)[0]
-            ha.slots_in, ha.slots_out = slots_ptr(slots_from), CP["slots"] + a * CS["slots"]
+            ha.H_par, ha.slots_in, ha.slots_out = hp0, sp0, CP["slots"] + a * CS["slots"]
             ha.surprise = CP["surprise_o"] + a * CS["surprise_o"] if afd else None
             ha.logits = CP["logits"] + a * CS["logits"]
-            ha.stats = lsp + (8 + 4 * b) * 4
-            rc = heads_fwd(ctypes.byref(ha), stream)
+            ha.stats = lsp + 8 * 4
+            rc = heads_fwd(ha_ref, st)
             if rc:
                 check(rc, "ic_heads_fwd")
+            return True
 
-        def verify(cur: int, b: int, stream) -> None:
-            ver = vers[b]
-            ver[0].x0 = CP["H"] + (i0 + cur) * CS["H"] + motor * d * 4
-            ver[2].y = lsp + (48 + b) * 4
-            rc = vscore(ver, 3, lsp + (8 + 4 * b) * 4, lsp + b * 4, stream)
+        def verify(first: int, n: int) -> None:
+            """Verifier energy + branch score of n consecutive steps (batched layers)."""
+            ver[0].x0 = CP["H"] + (i0 + first) * CS["H"] + motor * d * 4
+            ver[2].y = lsp + 48 * 4
+            for g in ver:
+                g.nbatch = n
+            rc = vscore(ver, 3, lsp + 8 * 4, lsp, st)
             if rc:
                 check(rc, "ic_verify_score")
 
         last = -1
         traces: List[torch.Tensor] = []
-        if not cfg.train_deterministic_inner_loop and (vers[0] is None or steer is None):
+        if not cfg.train_deterministic_inner_loop and (ver is None or steer is None):
             raise RuntimeError("the branching reasoning loop needs the planner, critic and energy verifier "
                                "(reference model.py:376-438)")
         if cfg.train_deterministic_inner_loop:
@@ -490,33 +514,25 @@ class LoopEngine:
                 gate.value_bias = 0.0
                 par = cur
                 cur = step(par, k, u_mean, 0)
-                heads(cur, par, par, 0, st)
+                heads([cur], [par], [par])
                 traces.append(keep(H_of(cur)))
                 if k + 1 < K_inner:
                     u_mean = float(ls[8])  # utils.py:127-130 of this step's logits (host sync)
             return cur, cur, traces
 
         B_br = cfg.B_br
-        main = torch.cuda.current_stream(dev)
-        side = hs["side"] if self.two_streams else None
-        sx = ctypes.c_void_p(side.cuda_stream) if side is not None else st
-        ev_front, ev_reg, ev_side = hs["ev_front"], hs["ev_reg"], hs["ev_side"]
-        side_busy = False
         branches = [(-1, -1) for _ in range(B_br)]  # (step whose workspace slots, step whose H / mask)
         u_mean = 0.0
         for k in range(K_inner):
-            if side_busy:  # the earlier branches' scores of the previous iteration come from the side stream
-                main.wait_event(ev_side)
-                side_busy = False
             # planner / critic on the best candidate so far, chosen on the device (model.py:371-386)
             sa.n_cand = len(branches)
             for c, (_, hstep) in enumerate(branches):
-                sa.H_cand[c], sa.mask_cand[c] = ptr_of(hstep)
+                sa.H_cand[c], sa.mask_cand[c] = in_ptrs(hstep, c)
             sa.scores = lsp if k > 0 else None
             rc = steer_sel(sa_ref, st) or chain(steer, 6, st)
             if rc:
                 check(rc, "ic_steer_select/ic_gemv_chain")
-            vals = ls.tolist()  # the one host sync of this outer iteration (everything before it is complete)
+            vals = ls.tolist()  # the one host sync of this outer iteration
             if k > 0:
                 top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
                 branches = [branches[i] for i in top]
@@ -525,38 +541,18 @@ class LoopEngine:
             v_hat = vals[40]
             gate.value_bias = v_hat
             burst = schedule_burst(u_mean, v_hat, m.R)
-            # gate + router: branch 0 on the main stream, the others on the side stream
-            ids = []
-            for b in range(B_br):
-                on_side = side is not None and b > 0
-                ids.append(front(branches[b][1], k, u_mean, burst, sx if on_side else st))
-                if on_side:
-                    ev_front[b].record(side)
-            # region phases back to back on the main stream (they share the state chain);
-            # heads + verifier of every branch but the last on the side stream
-            for b in range(B_br):
-                sl, par = branches[b]
-                cur = ids[b]
-                if side is not None and b > 0:
-                    main.wait_event(ev_front[b])
+            pars = [branches[b][1] for b in range(B_br)]   # IndexError for B_br > 2, as in the reference
+            sls = [branches[b][0] for b in range(B_br)]
+            ids = front(pars, k, u_mean, burst, st)          # gate + router of every branch
+            for cur in ids:                                  # region phases share the state chain
                 region(cur, st)
-                if side is not None and b < B_br - 1:
-                    ev_reg[b].record(main)
-                    side.wait_event(ev_reg[b])
-                    heads(cur, par, sl, b, sx)
-                    verify(cur, b, sx)
-                    side_busy = True
-                else:
-                    heads(cur, par, sl, b, st)
-                    verify(cur, b, st)
-                branches[b] = (cur, cur)
-                last = cur
-            if side_busy:
-                ev_side.record(side)
+            if not heads(ids, pars, sls):
+                raise RuntimeError("LoopEngine: branch inputs are not equally spaced (B_br > 2 is not supported)")
+            verify(ids[0], len(ids))
+            branches = [(cur, cur) for cur in ids]
+            last = ids[-1]
             if should_halt(None, u_mean, k, K_inner):
                 break
-        if side_busy:
-            main.wait_event(ev_side)
         vals = ls.tolist()
         top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
         branches = [branches[i] for i in top]

@@ -22,6 +22,7 @@ _SCALARS = {
     "float": ctypes.c_float,
     "double": ctypes.c_double,
     "uint8_t": ctypes.c_uint8,
+    "int64_t": ctypes.c_int64,
 }
 
 

@@ -84,9 +84,9 @@ def test_heads_fwd_vs_oracle(name, n_active):
     assert torch.equal(out_slots.cpu() != 0, orc.work.slots != 0), "workspace KWTA winners differ"
     close(out_slots, orc.work.slots, what="slots")
     close(out_logits, logits, what="logits")
-    close(buf["probs"], p, what="probs")
+    close(buf["probs"][0], p, what="probs")
     close(st, stats, rtol=1e-4, atol=1e-6, what="stats")
-    close(buf["aux"][1], surprise.mean(), what="aux surprise")
+    close(buf["aux"][0, 1], surprise.mean(), what="aux surprise")
     # the product's differentiable PyTorch heads (general path) agree with the kernel
     with torch.no_grad():
         prod.work.slots = t["slots"].clone()
@@ -143,8 +143,8 @@ def test_steer_chain_and_verify_score_vs_oracle():
         E = orc.verify(motor_state, probs, aux=aux)
         score = 0.6 * stats[2] + 0.2 * (-E) + 0.2 * stats[1]
     ms = motor_state.to(DEV)
-    buf["probs"].copy_(probs)
-    buf["aux"][:3].copy_(aux)
+    buf["probs"][0].copy_(probs)
+    buf["aux"][0, :3].copy_(aux)
     stats_d, score_d = stats.to(DEV), torch.zeros(1, device=DEV)
     ver = hs["ver"]
     ver[0].x0 = ms.data_ptr()
