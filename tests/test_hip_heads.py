@@ -165,3 +165,101 @@ def test_gemv_chain_rejects_bad_descriptors():
     d = (G * 1)()
     rc = hip.lib().ic_gemv_chain(d, 1, hip.stream_handle())
     assert rc == hip.ENUMS["IC_EINVAL"] and b"ic_gemv_chain" in hip.lib().ic_last_error()
+
+
+def test_strided_streams_equal_separate_calls():
+    """The batched-branch launches: gate + router with the two streams' inputs in REVERSED slot
+    order (negative stream stride) must equal two single-stream calls; same for the batched heads
+    and verifier chain."""
+    import ironcortex_amd as ic
+    from ironcortex_amd import hip
+    from ironcortex_amd.hip import ops
+    cfg, prod, _ = build_pair("allflags")
+    R, d, V = cfg.R, cfg.d, cfg.V
+    dev = torch.device(DEV)
+    L, st = hip.lib(), hip.stream_handle()
+    g = torch.Generator().manual_seed(3)
+    H2 = (torch.randn(2, R, d, generator=g) * (torch.rand(2, R, d, generator=g) < 0.3)).to(DEV)
+    mp2 = (torch.rand(2, R, generator=g) < 0.6).to(torch.uint8).to(DEV)
+    mp2[:, 0] = 1
+    gate, router = prod.gate, prod.router
+    off, nbr = gate._tables(dev)
+    tables = router._edge_tables(prod.reg_coords)
+    ebias = router._edge_bias(prod.reg_coords).detach().contiguous()
+    E = router.E
+
+    def run(S, Hptr, mptr, hs, ms):
+        out = dict(scores=torch.zeros(S, R, device=DEV), mask=torch.zeros(S, R, dtype=torch.uint8, device=DEV),
+                   M=torch.zeros(S, R, d, device=DEV), msg=torch.zeros(S, E, d, device=DEV),
+                   keyv=torch.zeros(S, E, d, device=DEV), q=torch.zeros(S, R, d, device=DEV), wgt=torch.zeros(S, E, device=DEV))
+        fa = torch.ones(S, dtype=torch.uint8, device=DEV)
+        ga = hip.new("ic_gate_args", S=S, R=R, d=d, sensor_idx=0, motor_idx=R - 1, k_total=5, force_io=1, w1=1.0, w2=0.3,
+                     w3=0.5, w4=0.2, t5=0.1, t6=0.05, gain_ema=gate.gain_ema, homeo=gate.homeo, focus_any=fa,
+                     nbr_off=off, nbr=nbr, scores=out["scores"], mask=out["mask"])
+        ga.H, ga.H_sstride = Hptr, hs
+        hip.check(L.ic_gate_fwd(ctypes.byref(ga), st), "gate")
+        spec = ops.RouterSpec(R, d, E, router.nW, True)
+        ra = ops._router_args(spec, tables, router._params(), S)
+        ra.ebias, ra.H, ra.mask_prev, ra.H_sstride, ra.mask_sstride = ebias.data_ptr(), Hptr, mptr, hs, ms
+        for k in ("M", "msg", "keyv", "q", "wgt"):
+            hip.set_field(ra, k, out[k])
+        hip.check(L.ic_router_fwd(ctypes.byref(ra), st), "router")
+        torch.cuda.synchronize()
+        return out
+
+    # streams in reversed slot order: stream 0 reads H2[1], stream 1 reads H2[0]
+    both = run(2, H2[1].data_ptr(), mp2[1].data_ptr(), -R * d, -R)
+    for s_, src in ((0, 1), (1, 0)):
+        one = run(1, H2[src].data_ptr(), mp2[src].data_ptr(), 0, 0)
+        for k in one:
+            assert torch.equal(both[k][s_], one[k][0]), (k, s_)
+
+    # batched heads + verifier == one step at a time
+    hs_ = prod.engine._heads_setup(dev)
+    ha, ver, buf = hs_["ha"], hs_["ver"], hs_["buf"]
+    Hc = (torch.randn(2, R, d, generator=g) * (torch.rand(2, R, d, generator=g) < 0.2)).to(DEV)
+    mk = (torch.rand(2, R, generator=g) < 0.5).to(torch.uint8).to(DEV)
+    mk[:, 0] = mk[:, R - 1] = 1
+    slots_in = torch.randn(2, 8, d, generator=g).to(DEV)
+    sur = torch.rand(2, R, generator=g).to(DEV)
+
+    def run_heads(S, first, hp, hps, sp, sps):
+        o = dict(slots=torch.zeros(S, 8, d, device=DEV), logits=torch.zeros(S, V, device=DEV))
+        ls = torch.zeros(64, device=DEV)
+        ha.S, ha.Hpar_sstride, ha.slots_in_sstride = S, hps, sps
+        ha.H, ha.mask, ha.surprise = Hc[first].data_ptr(), mk[first].data_ptr(), sur[first].data_ptr()
+        ha.H_par, ha.slots_in = hp, sp
+        ha.slots_out, ha.logits, ha.stats = o["slots"].data_ptr(), o["logits"].data_ptr(), ls.data_ptr() + 32
+        ha.aux_surprise = buf["aux"].data_ptr() + 4
+        hip.check(L.ic_heads_fwd(ctypes.byref(ha), st), "heads")
+        ver[0].x0 = Hc[first].data_ptr() + (R - 1) * d * 4
+        ver[2].y = ls.data_ptr() + 48 * 4
+        for g_ in ver:
+            g_.nbatch = S
+        hip.check(L.ic_verify_score(ver, 3, ls.data_ptr() + 32, ls.data_ptr(), st), "verify")
+        torch.cuda.synchronize()
+        o["ls"] = ls.clone()
+        return o
+
+    both = run_heads(2, 0, H2[1].data_ptr(), -R * d, slots_in[1].data_ptr(), -8 * d)
+    for s_, src in ((0, 1), (1, 0)):
+        # single call for step s_ (its scratch is block 0, its statistics land at ls[8:12], score ls[0])
+        ha_H, ha_m, ha_s = Hc[s_], mk[s_], sur[s_]
+        o = dict(slots=torch.zeros(1, 8, d, device=DEV), logits=torch.zeros(1, V, device=DEV))
+        ls = torch.zeros(64, device=DEV)
+        ha.S, ha.Hpar_sstride, ha.slots_in_sstride = 1, 0, 0
+        ha.H, ha.mask, ha.surprise = ha_H.data_ptr(), ha_m.data_ptr(), ha_s.data_ptr()
+        ha.H_par, ha.slots_in = H2[src].data_ptr(), slots_in[src].data_ptr()
+        ha.slots_out, ha.logits, ha.stats = o["slots"].data_ptr(), o["logits"].data_ptr(), ls.data_ptr() + 32
+        hip.check(L.ic_heads_fwd(ctypes.byref(ha), st), "heads")
+        ver[0].x0 = ha_H.data_ptr() + (R - 1) * d * 4
+        for g_ in ver:
+            g_.nbatch = 1
+        hip.check(L.ic_verify_score(ver, 3, ls.data_ptr() + 32, ls.data_ptr(), st), "verify")
+        torch.cuda.synchronize()
+        assert torch.equal(both["slots"][s_], o["slots"][0]) and torch.equal(both["logits"][s_], o["logits"][0])
+        assert torch.equal(both["ls"][8 + 4 * s_: 12 + 4 * s_], ls[8:12]), "statistics"
+        # (a single small chain runs in the one-workgroup kernel, the batched one layer by layer:
+        # different summation order, so tolerance instead of bit equality)
+        close(both["ls"][s_], ls[0].cpu(), rtol=1e-5, atol=1e-6, what="score")
+        close(both["ls"][48 + s_], ls[48].cpu(), rtol=1e-5, atol=1e-6, what="energy")
