@@ -253,6 +253,7 @@ def test_strided_streams_equal_separate_calls():
         ha.slots_out, ha.logits, ha.stats = o["slots"].data_ptr(), o["logits"].data_ptr(), ls.data_ptr() + 32
         hip.check(L.ic_heads_fwd(ctypes.byref(ha), st), "heads")
         ver[0].x0 = ha_H.data_ptr() + (R - 1) * d * 4
+        ver[2].y = ls.data_ptr() + 48 * 4
         for g_ in ver:
             g_.nbatch = 1
         hip.check(L.ic_verify_score(ver, 3, ls.data_ptr() + 32, ls.data_ptr(), st), "verify")
