@@ -73,7 +73,7 @@ class _Sample:
     """Record of one loop: what the backward needs to replay the steps in reverse."""
 
     __slots__ = ("chunk", "i0", "n", "parent", "best", "step_pos", "init", "H0", "mask0", "sensor", "ebias",
-                 "norm_in_w", "flags", "kwta_k", "kwta_temp", "keep")
+                 "norm_in_w", "flags", "kwta_k", "kwta_temp", "keep", "ebias_grad")
 
 
 class LoopEngine:
@@ -84,6 +84,10 @@ class LoopEngine:
         self._arena_key = None
         self._ws = None
         self._state_in_arena = False
+        self._unit_log = []
+        self._in_cache = None
+        self._pass = None  # accumulators of the backward pass in flight
+        model._coord.register(self._begin_pass, self._finish_pass)
 
     # ------------------------------------------------------------------ applicability
     def usable(self, H_prev: torch.Tensor, logits_need_grad: bool) -> bool:
@@ -103,6 +107,7 @@ class LoopEngine:
         """Start of a new forward/backward pass: every step slot may be reused.  The bank's state
         tensors are views of the last loop's final slot until now; copy them out first."""
         self._rescue_state()
+        self.flush_units()
         if self._arena is not None:
             self._arena.reset()
 
@@ -202,8 +207,13 @@ class LoopEngine:
         nbr_ = 1 if cfg.train_deterministic_inner_loop else max(1, cfg.B_br)
         focus_any = (focus_map.any().to(_U8).reshape(1) if focus_map.numel() > 0
                      else torch.ones(1, dtype=_U8, device=dev)).repeat(nbr_)
-        H0 = H_prev.detach().float().reshape(1, R, d).repeat(nbr_, 1, 1)
-        mask0 = reg_mask_prev.to(_U8).reshape(1, R).repeat(nbr_, 1)
+        ikey = (H_prev.data_ptr(), H_prev._version, reg_mask_prev.data_ptr(), reg_mask_prev._version, nbr_)
+        if self._in_cache is not None and self._in_cache[0] == ikey:
+            H0, mask0 = self._in_cache[1], self._in_cache[2]  # same (unmodified) tensors as the last loop
+        else:
+            H0 = H_prev.detach().float().reshape(1, R, d).repeat(nbr_, 1, 1)
+            mask0 = reg_mask_prev.to(_U8).reshape(1, R).repeat(nbr_, 1)
+            self._in_cache = (ikey, H0, mask0, H_prev, reg_mask_prev)
         off, nbr = gate._tables(dev)
 
         # ---- structs: everything static is set once per loop
@@ -344,8 +354,10 @@ class LoopEngine:
             if prec:
                 router._last_wgt = f["wgt"][li:li + 1, :E]
             self._state_in_arena = True
-        if m._units is not None and E > 0 and n > 0:
-            self._count_units(chunk, i0, parent, mask0[0])
+        if m._units is not None and E > 0 and n > 0:  # bench.py's device-side unit counters
+            self._unit_log.append((chunk, i0, list(parent), mask0[0]))
+            if not grad:
+                self.flush_units()
 
         reg_mask = mask_of(best).bool()
         if grad and n > 0:
@@ -354,20 +366,37 @@ class LoopEngine:
             s.init, s.H0, s.mask0, s.sensor, s.ebias, s.norm_in_w = init, H0, mask0, sens_c, ebias_c, norm_in_w
             s.flags, s.kwta_k, s.kwta_temp = flags, kw_k, kw_temp
             s.keep = (focus_any, tables, rP, bP)
-            H_cur = LoopFn.apply(sensor, ebias, norm_in_w, bank.anchor(dev), self, s)
+            s.ebias_grad = bool(ebias.requires_grad)
+            H_cur = LoopFn.apply(sensor, bank.anchor(dev), self, s)
         else:
             H_cur = H_of(best).clone()
         return H_cur, reg_mask, last_logits, traces
 
-    def _count_units(self, chunk, i0, parent, mask0) -> None:
+    def flush_units(self) -> None:
+        """Add the logged loops' region steps / active edges / destination regions to the model's
+        counters: one batch of ops per arena chunk instead of one per loop."""
         m = self.model
-        n = len(parent)
-        masks = chunk.fields["mask"][i0:i0 + n].float()
-        allm = torch.cat([mask0.float().reshape(1, -1), masks], 0)
-        prev = allm[torch.tensor([p + 1 for p in parent], device=masks.device)]  # [n,R]
-        ea = prev[:, m.router.src_idx]  # [n,E]
-        into = torch.zeros(n, m.R, device=masks.device).index_add_(1, m.router.dst_idx, ea)
-        m._units += torch.stack([masks.sum(), ea.sum(), (into > 0).sum().float()])
+        log, self._unit_log = self._unit_log, []
+        if m._units is None or not log:
+            return
+        by_chunk = {}
+        for chunk, i0, parent, mask0 in log:
+            by_chunk.setdefault(id(chunk), (chunk, []))[1].append((i0, parent, mask0))
+        for chunk, loops in by_chunk.values():
+            field = chunk.fields["mask"]
+            dev = field.device
+            extra = torch.stack([mk for _, _, mk in loops]).float()  # the loops' own reg_mask_prev rows
+            cap = field.shape[0]
+            steps, prevs = [], []
+            for li, (i0, parent, _) in enumerate(loops):
+                for t, par in enumerate(parent):
+                    steps.append(i0 + t)
+                    prevs.append(i0 + par if par >= 0 else cap + li)
+            allm = torch.cat([field.float(), extra], 0)
+            masks = allm[torch.tensor(steps, device=dev)]
+            ea = allm[torch.tensor(prevs, device=dev)][:, m.router.src_idx]  # [n,E]
+            into = torch.zeros(len(steps), m.R, device=dev).index_add_(1, m.router.dst_idx, ea)
+            m._units += torch.stack([masks.sum(), ea.sum(), (into > 0).sum().float()])
 
     # ------------------------------------------------------------------ loop heads (HIP, no autograd)
     def _heads_setup(self, dev):
@@ -697,29 +726,60 @@ class LoopEngine:
                     Z["gH"][par].add_(ws["gH_tmp"].reshape(-1))
                 has_grad[par] = True
 
-        # ---- small parameter gradients: one reduction per loop
+        # ---- the small parameter gradients are reduced ONCE per backward pass (_finish_pass): the
+        # per-step rows of this loop are only queued here
+        self._pass["blocks"].append((Z, n_r, s))
+        return Z["gsens"].view(n_r * 2, d).sum(0)
+
+    # ------------------------------------------------------------------ per-pass reductions
+    def _begin_pass(self) -> None:
+        self._pass = {"blocks": []}
+
+    def _finish_pass(self) -> None:
+        """End of a backward pass: sum the queued per-step gradient rows of every loop and add
+        them to the parameters' gradients (region norms / decay / noise levels, raw_P, norm_in,
+        and the Fourier edge-bias coefficients through the closed form of gate.py:284-290)."""
+        ps, self._pass = self._pass, None
+        if not ps or not ps["blocks"]:
+            return
+        m = self.model
+        bank, router = m.bank, m.router
+        R, d, E = m.R, m.d, router.E
+        Ez = max(E, 1)
+        blocks = ps["blocks"]
+        s0 = blocks[0][2]
+        flags = s0.flags
+        afd, rt_ = bool(flags & ops.IC_F_AFD), bool(flags & ops.IC_F_RT)
+        prec = router.enable_precision_routed_messages
+        tot = lambda k: torch.cat([Z[k] for Z, _, _ in blocks], 0)  # [sum n_r, size]
         sink = bank._grad_sink(0)
-        sink("norm_w", Z["g_norm_w_rows"].sum(0).view(R, d))
-        sink("raw_decay", Z["g_raw_decay_rows"].sum(0).view(R, d))
+        sink("norm_w", tot("g_norm_w_rows").sum(0).view(R, d))
+        sink("raw_decay", tot("g_raw_decay_rows").sum(0).view(R, d))
         if afd:
             if flags & ops.IC_F_NOISE_VEC:
-                sink("pn_param", Z["g_pn_rows"].sum(0).view(R, d))
-                sink("on_param", Z["g_on_rows"].sum(0).view(R, d))
+                sink("pn_param", tot("g_pn_rows").sum(0).view(R, d))
+                sink("on_param", tot("g_on_rows").sum(0).view(R, d))
             else:
-                sink("pn_param", Z["g_pn_rows"].view(n_r, R, d).sum((0, 2)))
-                sink("on_param", Z["g_on_rows"].view(n_r, R, d).sum((0, 2)))
+                sink("pn_param", tot("g_pn_rows").view(-1, R, d).sum((0, 2)))
+                sink("on_param", tot("g_on_rows").view(-1, R, d).sum((0, 2)))
         if rt_:
-            rn = Z["g_rnoise_rows"].sum(0).view(R, 2)
+            rn = tot("g_rnoise_rows").sum(0).view(R, 2)
             sink("rpn_param", rn[:, 0].contiguous())
             sink("ron_param", rn[:, 1].contiguous())
-        g_ebias = None
+
+        def accumulate(p, g):
+            if p.requires_grad:
+                p.grad = g if p.grad is None else p.grad + g
+
+        accumulate(s0.norm_in_w, tot("g_norm_in_rows").view(-1, d).sum(0))
         if E > 0:
-            g_ebias = Z["g_ebias_part"].view(n_r * ns, Ez).sum(0)[:E]
             if prec:
-                router._grad_sink("raw_P", Z["g_rawP_rows"].sum(0).view(Ez, d)[:E], tables["widx_long"])
-        g_sensor = Z["gsens"].view(n_r * 2, d).sum(0)
-        g_norm_in = Z["g_norm_in_rows"].view(n_r * R, d).sum(0)
-        return g_sensor, g_ebias, g_norm_in
+                router._grad_sink("raw_P", tot("g_rawP_rows").sum(0).view(Ez, d)[:E], s0.keep[1]["widx_long"])
+            if s0.ebias_grad:  # ebias = 1 + fb_alpha * fb_scale * sum_m(cos S * beta_cos + sin S * beta_sin)
+                g_eb = tot("g_ebias_part").view(-1, Ez).sum(0)[:E] * (router.fb_alpha * router.fb_scale)
+                _, cosS, sinS = router._geom
+                accumulate(router.beta_cos, g_eb @ cosS)
+                accumulate(router.beta_sin, g_eb @ sinS)
 
 
 class LoopFn(torch.autograd.Function):
@@ -727,15 +787,12 @@ class LoopFn(torch.autograd.Function):
     (already computed by LoopEngine.run), backward replays the recorded steps in reverse."""
 
     @staticmethod
-    def forward(ctx, sensor, ebias, norm_in_w, anchor, engine, sample):
+    def forward(ctx, sensor, anchor, engine, sample):
         ctx.engine, ctx.sample = engine, sample
-        ctx.shapes = (sensor.shape, ebias.shape)
+        ctx.sshape = sensor.shape
         return sample.chunk.fields["H"][sample.i0 + sample.best].clone()
 
     @staticmethod
     def backward(ctx, gH):
-        g_sensor, g_ebias, g_norm_in = ctx.engine.backward(ctx.sample, gH.contiguous())
-        sshape, eshape = ctx.shapes
-        if g_ebias is None:
-            g_ebias = torch.zeros(eshape, device=gH.device)
-        return g_sensor.view(sshape), g_ebias.view(eshape), g_norm_in, None, None, None
+        g_sensor = ctx.engine.backward(ctx.sample, gH.contiguous())
+        return g_sensor.view(ctx.sshape), None, None, None

@@ -114,6 +114,7 @@ class CortexReasoner(nn.Module):
         self.counters["inner_steps"] = 0
 
     def read_units(self) -> Dict[str, float]:
+        self.engine.flush_units()
         u = self._units.tolist() if self._units is not None else [0.0, 0.0, 0.0]
         return {"inner_steps": self.counters["inner_steps"], "region_steps": u[0], "active_edges": u[1],
                 "dst_regions": u[2]}
@@ -381,9 +382,10 @@ class CortexReasoner(nn.Module):
         if N > 1 and tokens_batch.is_cuda and not self.cfg.ff_dropout and not self.cfg.profile:
             batched = self.sensor_vectors_batch(tokens_batch, focus_batch)  # the loops only differ in region state
         try:
+            H_zero, mask_zero = self.zeros_state(dev)  # never written to: shared by all loops
             for b in range(N):
                 self.detach_state()
-                H_prev, mask_prev = self.zeros_state(dev)
+                H_prev, mask_prev = H_zero, mask_zero
                 if batched is not None:  # what a per-sequence mixer call would have left behind
                     self._sensor_override = batched[0][b]
                     self.local_mix.last_energy = batched[1][b]
