@@ -116,3 +116,11 @@ class TokenHead_MFS(nn.Module):
         per_facet = torch.stack([f(x) for f in self.facets], dim=0)
         logits = (g.unsqueeze(-1) * per_facet).sum(dim=0)
         return logits, {"facet_balance": (g.mean() - 1.0 / self.Kf).pow(2)}
+
+    def forward_rows(self, X: torch.Tensor):
+        """forward() of every row of X [B,d] in one pass: (logits [B,V], facet_balance [B])."""
+        W, b = self.stacked()
+        z = F.linear(X, W, b)  # [B, Kf + Kf*V]
+        g = F.softmax(z[:, : self.Kf], dim=-1)
+        logits = (g.unsqueeze(-1) * z[:, self.Kf:].view(-1, self.Kf, self.V)).sum(dim=1)
+        return logits, (g.mean(dim=-1) - 1.0 / self.Kf).pow(2)

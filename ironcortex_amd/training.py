@@ -116,19 +116,18 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     rtd_loss = F.cross_entropy(rtd_logits, rtd_target)
     rtd_acc = (rtd_logits.argmax(dim=-1) == rtd_target).float().mean()
 
-    # ---- denoising (mask-predict): first masked position of each negative
+    # ---- denoising (mask-predict): first masked position of each negative (training.py:170-186);
+    # the token head runs once for all rows instead of once per sample
     denoise_loss = torch.tensor(0.0, device=device)
-    hits: List[torch.Tensor] = []
-    for b in range(B):
-        logits_b, aux_b = model.lm_head(motor_neg[b])
-        if bool(d_masks[b].any()):  # host tensors: no device sync
-            idx = int(d_masks[b].nonzero(as_tuple=False)[0].item())
-            target = d_targets[b][idx].unsqueeze(0).to(device)
-            denoise_loss = denoise_loss + F.cross_entropy(logits_b.unsqueeze(0), target) \
-                + aux_b.get("facet_balance", torch.tensor(0.0, device=device)) * λ.facet
-            hits.append((logits_b.argmax(dim=-1) == target[0]).float())
-    denoise_loss = denoise_loss / max(1, B)
-    denoise_acc = torch.stack(hits).mean() if hits else torch.tensor(0.0, device=device)
+    denoise_acc = torch.tensor(0.0, device=device)
+    rows = [b for b in range(B) if bool(d_masks[b].any())]  # host tensors: no device sync
+    if rows:
+        first = [int(d_masks[b].nonzero(as_tuple=False)[0].item()) for b in rows]
+        target = torch.stack([d_targets[b][i] for b, i in zip(rows, first)]).to(device)
+        sel = torch.tensor(rows, device=device)
+        logits_d, facet = model.lm_head.forward_rows(motor_neg[sel])
+        denoise_loss = (F.cross_entropy(logits_d, target, reduction="sum") + λ.facet * facet.sum()) / max(1, B)
+        denoise_acc = (logits_d.argmax(dim=-1) == target).float().mean()
 
     # ---- critic regression
     critic_loss = torch.tensor(0.0, device=device)
