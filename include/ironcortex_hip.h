@@ -211,6 +211,7 @@ typedef struct ic_router_bwd_args {
   float* gHd;    /* [S,R,d] precision only: direct d/dH_dst */
   float* slab;   /* [nslab,S,E,d], nslab = ic_bwd_nslab(d) */
   float* slab_q; /* [nslab,S,R,d] precision only */
+  int64_t gH_sstride; /* elements between consecutive streams' gH blocks; 0 = contiguous (R*d) */
 } ic_router_bwd_args;
 int ic_router_bwd(const ic_router_bwd_args* a, ic_stream_t stream);
 

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void k_router_gather_bwd(ic_router_bwd_args b,
       sum_slabs(g, b.slab + ((size_t)s * a.E + e) * d, (size_t)SE * d, nslab, d, lane);
     }
   }
-  store_row(g, b.gH + (size_t)row * d, d, lane);
+  store_row(g, b.gH + (int64_t)s * (b.gH_sstride ? b.gH_sstride : (int64_t)a.R * d) + (size_t)r * d, d, lane);
 }
 
 // ---------------------------------------------------------------- deferred edge weight gradient

@@ -162,8 +162,8 @@ class LoopEngine:
         R, d, E = m.R, m.d, max(m.router.E, 1)
         ns = ops.bwd_nslab(d)
         z = lambda *s: torch.zeros(*s, device=device)
-        ws = {"gM": z(R, d), "ghpre": z(R, d), "gy": z(R, d), "slab": z(ns, R, d), "slab_rt": z(ns, R),
-              "gH_tmp": z(R, d), "gHd": z(R, d), "rslab": z(ns, E, d), "slab_q": z(ns, R, d)}
+        ws = {"gM": z(2, R, d), "ghpre": z(R, d), "gy": z(R, d), "slab": z(ns, R, d), "slab_rt": z(ns, R),
+              "gH_tmp": z(2, R, d), "gHd": z(2, R, d), "rslab": z(ns, 2, E, d), "slab_q": z(ns, 2, R, d)}
         for side in ("a", "b"):
             for k in ("gnum", "gden", "gvar", "gpred"):
                 ws[f"{k}_{side}"] = z(R, d)
@@ -656,7 +656,6 @@ class LoopEngine:
             rb.f = ops._router_args(rspec, tables, rP, 1)
             rb.f.ebias = s.ebias.data_ptr()
             rb.f.M = WP["gM"]  # unused by the backward, must be non-NULL
-            rb.gM = WP["gM"]
             rb.src_off, rb.src_edges = tables["src_off"].data_ptr(), tables["src_edges"].data_ptr()
             rb.slab, rb.gHd, rb.slab_q = WP["rslab"], WP["gHd"], WP["slab_q"]
         b_ref, rb_ref = ctypes.byref(b), ctypes.byref(rb)
@@ -674,7 +673,16 @@ class LoopEngine:
             + (["g_rnoise_rows"] if rt_ else [])
         side, have_state_grad = "a", False
         H0p, mask0p = s.H0.data_ptr(), s.mask0.data_ptr()
-        for t in range(n_r - 1, -1, -1):
+        nb0 = s.H0.shape[0]
+
+        def in_ptrs(par: int, b_: int):
+            if par < 0:
+                b_ = min(b_, nb0 - 1)
+                return H0p + b_ * R * d * 4, mask0p + b_ * R
+            return CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
+
+        def region_bwd(t: int, gM_ptr: int) -> None:
+            nonlocal side, have_state_grad
             a = i0 + t
             f = b.f
             f.step_pos = s.step_pos[t]
@@ -685,7 +693,7 @@ class LoopEngine:
                 f.radius_o = CP["radius_o"] + a * CS["radius_o"]
             for k in saved:
                 setattr(f, k, CP[k] + a * CS[k])
-            b.gH = zp["gH"] + t * R * d * 4
+            b.gH, b.gM = zp["gH"] + t * R * d * 4, gM_ptr
             other = "b" if side == "a" else "a"
             for g in gnames:
                 setattr(b, g + "_o", WP[f"{g}_{side}"] if have_state_grad else None)
@@ -699,32 +707,61 @@ class LoopEngine:
             if rc:
                 check(rc, "ic_region_phase_bwd")
             side, have_state_grad = other, True
-            if E == 0:
-                continue
-            par = s.parent[t]
+
+        def router_bwd(ts: List[int]) -> None:
+            """Router backward of the consecutive steps ts (1 or 2: the branches of one outer
+            iteration go through as two streams of one launch sequence)."""
+            n = len(ts)
+            tA = ts[0]
+            a = i0 + tA
+            pars = [s.parent[t] for t in ts]
             rf = rb.f
-            if par < 0:
-                rf.H, rf.mask_prev = H0p, mask0p
-            else:
-                rf.H, rf.mask_prev = CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
+            rf.S = n
+            rf.H, rf.mask_prev = in_ptrs(pars[0], 0)
+            rf.H_sstride = rf.mask_sstride = 0
+            direct = all(p_ >= 0 and not has_grad[p_] for p_ in pars) and len(set(pars)) == n
+            rb.gH_sstride = 0
+            if n == 2:
+                h1, m1 = in_ptrs(pars[1], 1)
+                rf.H_sstride, rf.mask_sstride = (h1 - rf.H) // 4, m1 - rf.mask_prev
+                if direct:
+                    rb.gH_sstride = (pars[1] - pars[0]) * R * d
             for k in rsaved:
                 setattr(rf, k, CP[k] + a * CS[k])
-            direct = par >= 0 and not has_grad[par]
-            rb.gH = zp["gH"] + par * R * d * 4 if direct else WP["gH_tmp"]
-            rb.g_ebias_part = zp["g_ebias_part"] + t * ns * Ez * 4
+            rb.gM = WP["gM"]
+            rb.gH = zp["gH"] + pars[0] * R * d * 4 if direct else WP["gH_tmp"]
+            rb.g_ebias_part = zp["g_ebias_part"] + tA * ns * Ez * 4
             if prec:
-                rb.g_rawP_rows = zp["g_rawP_rows"] + t * Ez * d * 4
+                rb.g_rawP_rows = zp["g_rawP_rows"] + tA * Ez * d * 4
             for k, fld in (("gmsg", "tape_gmsg"), ("H", "tape_H"), ("eact", "tape_eact"), ("gkey", "tape_gkey"),
                            ("gq", "tape_gq"), ("qact", "tape_qact")):
                 if k in RB:
-                    setattr(rb, fld, RB[k][0] + (rt0 + t) * RB[k][1])
+                    setattr(rb, fld, RB[k][0] + (rt0 + tA) * RB[k][1])
             rc = r_bwd(rb_ref, st)
             if rc:
                 check(rc, "ic_router_bwd")
-            if par >= 0:
-                if not direct:
-                    Z["gH"][par].add_(ws["gH_tmp"].reshape(-1))
-                has_grad[par] = True
+            for j_, p_ in enumerate(pars):
+                if p_ >= 0:
+                    if not direct:
+                        Z["gH"][p_].add_(ws["gH_tmp"][j_].reshape(-1))
+                    has_grad[p_] = True
+
+        # steps 2k, 2k+1 are the two branches of outer iteration k (branching loop, B_br == 2)
+        pairs = (not m.cfg.train_deterministic_inner_loop) and m.cfg.B_br == 2 and E > 0
+        gM0, gM1 = WP["gM"], WP["gM"] + R * d * 4
+        t = n_r - 1
+        while t >= 0:
+            if pairs and t % 2 == 1 and s.parent[t] != s.parent[t - 1] \
+                    and (s.parent[t] < 0) == (s.parent[t - 1] < 0):
+                region_bwd(t, gM1)
+                region_bwd(t - 1, gM0)
+                router_bwd([t - 1, t])
+                t -= 2
+            else:
+                region_bwd(t, gM0)
+                if E > 0:
+                    router_bwd([t])
+                t -= 1
 
         # ---- the small parameter gradients are reduced ONCE per backward pass (_finish_pass): the
         # per-step rows of this loop are only queued here
