@@ -105,8 +105,8 @@ def cpu_baseline(cfg_name: str, B: int, T: int, seed: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="10m")
     ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
     ap.add_argument("--seq", type=int, default=256)
