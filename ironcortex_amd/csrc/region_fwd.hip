@@ -459,7 +459,7 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
   if (a->d > 256 && rpb > 16) rpb = 16;  // register budget at DCH >= 2
   const dim3 gmat(ic_ceil_div(a->d, rpb), a->R);
   const float oma = (float)(1.0 - a->pred_alpha);
-  const bool fuse = a->S <= 2;  // prologue inside rkv
+  const bool fuse = a->S <= 2 && a->R <= 64;  // prologue inside rkv (measured a loss at R = 512)
 #define IC_FWD_LAUNCH(PP)                                                                                   \
   IC_DISPATCH_DCH(a->d, {                                                                                   \
     if (fuse) {                                                                                             \

@@ -24,52 +24,64 @@ __device__ __forceinline__ bool prev_on(const ic_router_args& a, int s, int r) {
 
 // ---------------------------------------------------------------- default forward
 // Workgroup = (8-row slice, destination r); incoming edges are walked in index order (the
-// reference's index_add_ order).  Streams are served SB at a time: an edge's two weight rows are
-// loaded once per batch of SB streams (not once per stream) and the batch's sender rows are all
-// requested before the first dot product is reduced.  Low register use on purpose: most
-// workgroups of a launch find no active edge and must come and go quickly.
-// (Tried and measured slower on MI355X at R=512: all <= 8 edges' rows in registers at once,
-// 64-113 us against 28 us -- the idle workgroups pay for the low occupancy.)
-template <int DCH, int SB>
-__global__ __launch_bounds__(256) void k_router_fwd(ic_router_args a) {
+// reference's index_add_ order).  Low register use on purpose: most workgroups of a launch find no
+// active edge and must come and go quickly.  (Tried and measured slower on MI355X at R=512: all
+// <= 8 edges' rows in registers at once, 64-113 us against 28 us; weights re-read per batch of 8
+// streams, 160 us against 76 us at S=8.)
+// An edge's two weight rows are loaded ONCE per 64 streams and only the streams
+// the edge is active in are visited (one ballot per edge); the per-stream sums live in LDS
+// (each wave owns its two rows of every stream: no conflicts, no barrier until the write-out),
+// accumulated edge by edge in index order.  R=512, k=32, d=256: 26 us at S=1 (1.9 TB/s), 76 us at
+// S=8 (4.1 TB/s), 278 us at S=64 (2.7 TB/s).
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_fwd_ms(ic_router_args a) {
+  __shared__ float acc[64][kRowsPerBlock];
   const int r = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
   const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
-  if (row0 >= d) return;
+  const bool rows_ok = row0 < d;  // d % 4 == 0: a wave's two rows are valid together
   const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
   const size_t dd = (size_t)d * d;
-  for (int s0 = 0; s0 < a.S; s0 += SB) {
-    float acc0[SB], acc1[SB];
-#pragma unroll
-    for (int i = 0; i < SB; ++i) acc0[i] = acc1[i] = 0.f;
-    for (int e = e0; e < e1; ++e) {
+  for (int sc = 0; sc < a.S; sc += 64) {
+    const int n = a.S - sc < 64 ? a.S - sc : 64;
+    if (lane < n) {
+      acc[lane][wave * 2] = 0.f;
+      acc[lane][wave * 2 + 1] = 0.f;
+    }
+    for (int e = e0; e < e1 && rows_ok; ++e) {
       const int src = a.src[e];
-      unsigned m = 0;
-#pragma unroll
-      for (int i = 0; i < SB; ++i)
-        if (s0 + i < a.S && prev_on(a, s0 + i, src)) m |= 1u << i;
-      if (!m) continue;
+      unsigned long long act = __ballot(lane < n && prev_on(a, sc + lane, src));
+      if (!act) continue;
       const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
-      RowFrag<DCH> w0, w1, h[SB];
+      RowFrag<DCH> w0, w1, h, hn;
       load_row(w0, W, d, lane);
       load_row(w1, W + d, d, lane);
       const float bias = a.ebias[e];
-#pragma unroll
-      for (int i = 0; i < SB; ++i)
-        if ((m >> i) & 1u) load_row(h[i], h_row(a, s0 + i, src), d, lane);
-#pragma unroll
-      for (int i = 0; i < SB; ++i) {
-        if ((m >> i) & 1u) {
-          const float m0 = wave_sum(dot_frag(w0, h[i])), m1 = wave_sum(dot_frag(w1, h[i]));
-          acc0[i] += m0 * bias;  // gate.py:290,324 (w == 1)
-          acc1[i] += m1 * bias;
+      int si = __ffsll((long long)act) - 1;
+      act &= act - 1;
+      load_row(h, h_row(a, sc + si, src), d, lane);
+      while (si >= 0) {
+        const int sn = act ? __ffsll((long long)act) - 1 : -1;
+        act &= act - 1;
+        if (sn >= 0) load_row(hn, h_row(a, sc + sn, src), d, lane);  // next stream's sender row in flight
+        const float m0 = wave_sum(dot_frag(w0, h)), m1 = wave_sum(dot_frag(w1, h));
+        if (lane == 0) {
+          acc[si][wave * 2] += m0 * bias;  // gate.py:290,324 (w == 1)
+          acc[si][wave * 2 + 1] += m1 * bias;
         }
+        h = hn;
+        si = sn;
       }
     }
-#pragma unroll
-    for (int i = 0; i < SB; ++i)
-      if (lane < 2 && s0 + i < a.S) a.M[((size_t)(s0 + i) * a.R + r) * d + row0 + lane] = lane ? acc1[i] : acc0[i];
+    __syncthreads();
+    // write-out: thread t -> (stream t / 8, row t % 8), 32 streams per pass
+    for (int base = 0; base < n; base += 32) {
+      const int s_l = base + (threadIdx.x >> 3), rr = threadIdx.x & 7;
+      const int row = blockIdx.x * kRowsPerBlock + rr;
+      if (s_l < n && row < d) a.M[((size_t)(sc + s_l) * a.R + r) * d + row] = acc[s_l][rr];
+    }
+    __syncthreads();
   }
 }
 
@@ -729,11 +741,7 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
     else if (a->d <= 512) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<2>, gcomb, dim3(256), 0, st, *a));
     else IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<4>, gcomb, dim3(256), 0, st, *a));
   } else {
-    // stream batch: 1 for a single stream (no extra registers), else 8 (4 at d > 512)
-    if (a->S == 1) IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<DCH, 1>), dim3(nsl, a->R), dim3(256), 0, st, *a)); });
-    else if (a->d <= 256) IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<1, 8>), dim3(nsl, a->R), dim3(256), 0, st, *a));
-    else if (a->d <= 512) IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<2, 8>), dim3(nsl, a->R), dim3(256), 0, st, *a));
-    else IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd<4, 4>), dim3(nsl, a->R), dim3(256), 0, st, *a));
+    IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL(k_router_fwd_ms<DCH>, dim3(nsl, a->R), dim3(256), 0, st, *a)); });
   }
   IC_LAUNCH_CHECK("ic_router_fwd");
   return IC_OK;

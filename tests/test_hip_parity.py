@@ -495,10 +495,11 @@ def test_router_multistream_and_empty():
     """S > 1 streams with different activity == per-stream oracle; no active sender -> zeros."""
     from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
     from oracle import hotpath as O
-    R, d, S = 10, 64, 3
+    R, d = 10, 64
     nb = hex_neighbors(R)
     E = sum(len(x) for x in nb)
-    for prec in (False, True):
+    # S = 3: stream-batched kernel; S = 12 (default routing): the LDS-accumulator kernel for many streams
+    for prec, S in ((False, 3), (True, 3), (False, 12)):
         t = gi.router_inputs(4242, R, d, E, "per_edge")
         router = make_router("ms", R, d, "per_edge", prec, t)
         coords = hex_axial_coords(R)
