@@ -27,12 +27,54 @@ from __future__ import annotations
 import ctypes
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from .hip import CLASSES, ENUMS, check, lib, new, ops, stream_handle
 from .utils import schedule_burst, should_halt
 
 _F32, _I32, _U8 = torch.float32, torch.int32, torch.uint8
+
+
+class StructImage:
+    """Per-step images of a C argument struct.  Most pointer fields of a step's arguments are
+    `base + t * stride` (step arena, tape, gradient rows); instead of ~50 ctypes attribute
+    writes per step, all steps' struct images are formed at once with numpy (int64 words) and a
+    step costs one memmove plus the few fields that do not advance linearly."""
+
+    def __init__(self, obj):
+        self.obj = obj
+        self.size = ctypes.sizeof(obj)
+        assert self.size % 8 == 0
+        self.addr = ctypes.addressof(obj)
+        self.stride = np.zeros(self.size // 8, dtype=np.int64)
+        self.lin = {}
+
+    @staticmethod
+    def _offset(cls, path):
+        off = 0
+        for name in path:
+            fld = getattr(cls, name)
+            off += fld.offset
+            cls = dict(cls._fields_)[name]
+        return off
+
+    def linear(self, path, base: int, stride: int) -> None:
+        """Field `path` (tuple of names, nested structs allowed) = base + t * stride."""
+        off = self._offset(type(self.obj), path)
+        assert off % 8 == 0
+        self.lin[off // 8] = (base, stride)
+
+    def images(self, ts) -> "np.ndarray":
+        """[len(ts), words] struct images for steps ts; call after every static field is set."""
+        base = np.frombuffer((ctypes.c_char * self.size).from_address(self.addr), dtype=np.int64).copy()
+        stride = np.zeros_like(base)
+        for w, (b0, st_) in self.lin.items():
+            base[w], stride[w] = b0, st_
+        return base[None, :] + np.asarray(ts, dtype=np.int64)[:, None] * stride[None, :]
+
+    def load(self, row) -> None:
+        ctypes.memmove(self.addr, row.ctypes.data, self.size)
 
 
 class _Chunk:
@@ -681,39 +723,63 @@ class LoopEngine:
                 return H0p + b_ * R * d * 4, mask0p + b_ * R
             return CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
 
+        # every linearly advancing field of the region backward, for all steps at once
+        bimg = StructImage(b)
+        sl0 = i0 * 1  # slot of step 0
+        for k in ("M", "mask"):
+            bimg.linear(("f", k), CP[k] + sl0 * CS[k], CS[k])
+        for k, ko in state_in:  # the step's input state = the previous step's output (t == 0: patched below)
+            bimg.linear(("f", k), CP[ko] + (sl0 - 1) * CS[ko], CS[ko])
+        if rt_:
+            bimg.linear(("f", "radius_o"), CP["radius_o"] + sl0 * CS["radius_o"], CS["radius_o"])
+        for k in saved:
+            bimg.linear(("f", k), CP[k] + sl0 * CS[k], CS[k])
+        bimg.linear(("gH",), zp["gH"], R * d * 4)
+        bimg.linear(("gsens",), zp["gsens"], 2 * d * 4)
+        for k in rows:
+            bimg.linear((k,), zp[k], zf[k] * 4)
+        for k, fld in (("g", "tape_g"), ("x", "tape_x"), ("o", "tape_o")):
+            bimg.linear((fld,), TB[k][0] + t0 * TB[k][1], TB[k][1])
+        b_rows = bimg.images(range(n_r))
+
         def region_bwd(t: int, gM_ptr: int) -> None:
             nonlocal side, have_state_grad
-            a = i0 + t
+            bimg.load(b_rows[t])
             f = b.f
             f.step_pos = s.step_pos[t]
-            f.M, f.mask = CP["M"] + a * CS["M"], CP["mask"] + a * CS["mask"]
-            for k, ko in state_in:  # the step's input state = the previous step's output
-                setattr(f, k, init[k] if t == 0 else CP[ko] + (a - 1) * CS[ko])
-            if rt_:
-                f.radius_o = CP["radius_o"] + a * CS["radius_o"]
-            for k in saved:
-                setattr(f, k, CP[k] + a * CS[k])
-            b.gH, b.gM = zp["gH"] + t * R * d * 4, gM_ptr
+            if t == 0:
+                for k, _ in state_in:
+                    setattr(f, k, init[k])
+            b.gM = gM_ptr
             other = "b" if side == "a" else "a"
             for g in gnames:
                 setattr(b, g + "_o", WP[f"{g}_{side}"] if have_state_grad else None)
                 setattr(b, g, WP[f"{g}_{other}"])
-            b.gsens = zp["gsens"] + t * 2 * d * 4
-            for k in rows:
-                setattr(b, k, zp[k] + t * zf[k] * 4)
-            for k, fld in (("g", "tape_g"), ("x", "tape_x"), ("o", "tape_o")):
-                setattr(b, fld, TB[k][0] + (t0 + t) * TB[k][1])
             rc = p_bwd(b_ref, st)
             if rc:
                 check(rc, "ic_region_phase_bwd")
             side, have_state_grad = other, True
+
+        if E > 0:
+            rimg = StructImage(rb)
+            for k in rsaved:
+                rimg.linear(("f", k), CP[k] + i0 * CS[k], CS[k])
+            rimg.linear(("g_ebias_part",), zp["g_ebias_part"], ns * Ez * 4)
+            if prec:
+                rimg.linear(("g_rawP_rows",), zp["g_rawP_rows"], Ez * d * 4)
+            for k, fld in (("gmsg", "tape_gmsg"), ("H", "tape_H"), ("eact", "tape_eact"), ("gkey", "tape_gkey"),
+                           ("gq", "tape_gq"), ("qact", "tape_qact")):
+                if k in RB:
+                    rimg.linear((fld,), RB[k][0] + rt0 * RB[k][1], RB[k][1])
+            rb.gM = WP["gM"]
+            r_rows = rimg.images(range(n_r))
 
         def router_bwd(ts: List[int]) -> None:
             """Router backward of the consecutive steps ts (1 or 2: the branches of one outer
             iteration go through as two streams of one launch sequence)."""
             n = len(ts)
             tA = ts[0]
-            a = i0 + tA
+            rimg.load(r_rows[tA])
             pars = [s.parent[t] for t in ts]
             rf = rb.f
             rf.S = n
@@ -726,17 +792,7 @@ class LoopEngine:
                 rf.H_sstride, rf.mask_sstride = (h1 - rf.H) // 4, m1 - rf.mask_prev
                 if direct:
                     rb.gH_sstride = (pars[1] - pars[0]) * R * d
-            for k in rsaved:
-                setattr(rf, k, CP[k] + a * CS[k])
-            rb.gM = WP["gM"]
             rb.gH = zp["gH"] + pars[0] * R * d * 4 if direct else WP["gH_tmp"]
-            rb.g_ebias_part = zp["g_ebias_part"] + tA * ns * Ez * 4
-            if prec:
-                rb.g_rawP_rows = zp["g_rawP_rows"] + tA * Ez * d * 4
-            for k, fld in (("gmsg", "tape_gmsg"), ("H", "tape_H"), ("eact", "tape_eact"), ("gkey", "tape_gkey"),
-                           ("gq", "tape_gq"), ("qact", "tape_qact")):
-                if k in RB:
-                    setattr(rb, fld, RB[k][0] + (rt0 + tA) * RB[k][1])
             rc = r_bwd(rb_ref, st)
             if rc:
                 check(rc, "ic_router_bwd")
