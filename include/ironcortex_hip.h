@@ -136,9 +136,11 @@ typedef struct ic_region_bwd_args {
   float* tape_x; /* [S,R,d]   operand of r,k,v (the normalised input x) */
   float* tape_o; /* [S,R,d]   operand of o (y, or dir under RT) */
   /* workspace */
-  float* ghpre;   /* [S,R,d] gradient w.r.t. the pre-KWTA activations */
-  float* gy;      /* [S,R,d] gradient w.r.t. y */
-  float* slab;    /* [nslab,S,R,d] partial transposed products; nslab = ic_region_bwd_nslab(d) */
+  float* ghpre;   /* [S,R,d] gradient w.r.t. the pre-KWTA activations (written only under soft KWTA;
+                     with hard KWTA it is gH * gate, recomputed where it is needed) */
+  float* slab;    /* [nslab,S,R,d] partial W_o^T g; nslab = ic_bwd_nslab(d) */
+  float* slab2;   /* [nslab,S,R,d] partial W_{r,k,v}^T g (must not alias slab: the kernel that
+                     writes slab2 is still reading slab) */
   float* slab_rt; /* [nslab,S,R] RT only: partial d/d radius' */
 } ic_region_bwd_args;
 

@@ -1,9 +1,12 @@
-// Region phase, backward.  Five launches mirror the forward in reverse:
-//   fin_bwd  (wave/row)   KWTA backward -> ghpre; inactive rows: trace/state pass-through grads
-//   out_bwd  (slice x r)  W_o^T ghpre -> slabs, tape g_o / operand
-//   mid_bwd  (wave/row)   slab reduce -> gy; radial-tangential scalar chain
-//   rkv_bwd  (slice x r)  state/WKV/AFD backward per channel, W_{r,k,v}^T g -> slabs, tape
-//   pro_bwd  (wave/row)   slab reduce + residual -> two RMSNorm backwards -> gM, gpred
+// Region phase, backward.  Three launches mirror the forward in reverse (four under soft KWTA):
+//   [fin_bwd (wave/row)   soft KWTA only: KWTA backward -> ghpre, inactive rows' pass-through.
+//                         With hard KWTA ghpre = gH * gate is recomputed by its two readers and
+//                         the pass-through moves into pro_bwd]
+//   out_bwd  (slice x r)  W_o^T ghpre -> slab, tape g_o / operand
+//   rkv_bwd  (slice x r)  slab reduce -> gy (+ radial-tangential scalar chain), state/WKV/AFD
+//                         backward per channel, W_{r,k,v}^T g -> slab2, tape
+//   pro_bwd  (wave/row)   slab2 reduce + residual -> two RMSNorm backwards -> gM, gpred;
+//                         inactive rows: trace/state pass-through grads
 // Weight gradients are deferred: see k_wgrad_region (one launch per backward pass).
 // Autograd of reference region.py:168-249, model.py:198-204,275-290.
 #include "ic_common.h"
@@ -25,6 +28,42 @@ __device__ __forceinline__ void load_opt(RowFrag<DCH>& f, const float* base, siz
     zero_frag(f);
 }
 
+// Inactive (stream, region) rows: the state passes through, the trace is an EMA of M
+// (region.py:140-146): gM = (1-alpha) gpred_o, gpred = alpha gpred_o.
+template <int DCH>
+__device__ __forceinline__ void inactive_passthrough(const ic_region_bwd_args& b, int row, int lane,
+                                                     float one_minus_alpha) {
+  const ic_region_args& a = b.f;
+  const int d = a.d;
+  const size_t off = (size_t)row * d;
+  RowFrag<DCH> g, t, gn, gd, gv;
+  load_opt(gn, b.gnum_o, off, d, lane);
+  load_opt(gd, b.gden_o, off, d, lane);
+  if (a.flags & IC_F_AFD) load_opt(gv, b.gvar_o, off, d, lane);
+  if (a.flags & IC_F_PRED) {
+    load_opt(g, b.gpred_o, off, d, lane);
+    const float al = (float)a.pred_alpha;
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      t.v[j] = make_float4(al * g.v[j].x, al * g.v[j].y, al * g.v[j].z, al * g.v[j].w);
+      g.v[j] = make_float4(one_minus_alpha * g.v[j].x, one_minus_alpha * g.v[j].y,
+                           one_minus_alpha * g.v[j].z, one_minus_alpha * g.v[j].w);
+    }
+    store_row(t, b.gpred + off, d, lane);
+    store_row(g, b.gM + off, d, lane);
+  } else {
+    zero_frag(g);
+    store_row(g, b.gM + off, d, lane);
+  }
+  store_row(gn, b.gnum + off, d, lane);
+  store_row(gd, b.gden + off, d, lane);
+  if (a.flags & IC_F_AFD) store_row(gv, b.gvar + off, d, lane);
+  if ((a.flags & IC_F_RT) && lane == 0) {
+    b.gradius[row] = b.gradius_o ? b.gradius_o[row] : 0.f;
+    b.gradius_var[row] = b.gradius_var_o ? b.gradius_var_o[row] : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------- finish backward
 template <int DCH>
 __global__ __launch_bounds__(256) void k_region_fin_bwd(ic_region_bwd_args b, float one_minus_alpha) {
@@ -34,7 +73,6 @@ __global__ __launch_bounds__(256) void k_region_fin_bwd(ic_region_bwd_args b, fl
   if (row >= a.S * a.R) return;
   const int d = a.d;
   const size_t off = (size_t)row * d;
-  const bool afd = a.flags & IC_F_AFD, rt = a.flags & IC_F_RT, pred = a.flags & IC_F_PRED;
   if (a.mask[row]) {
     RowFrag<DCH> g, gt, h;
     load_opt(g, b.gH, off, d, lane);
@@ -103,40 +141,13 @@ __global__ __launch_bounds__(256) void k_region_fin_bwd(ic_region_bwd_args b, fl
     }
     store_row(g, b.ghpre + off, d, lane);
   } else {
-    RowFrag<DCH> g, t;
-    if (pred) {
-      load_opt(g, b.gpred_o, off, d, lane);
-      const float al = (float)a.pred_alpha;
-#pragma unroll
-      for (int j = 0; j < DCH; ++j) {
-        t.v[j] = make_float4(al * g.v[j].x, al * g.v[j].y, al * g.v[j].z, al * g.v[j].w);
-        g.v[j] = make_float4(one_minus_alpha * g.v[j].x, one_minus_alpha * g.v[j].y,
-                             one_minus_alpha * g.v[j].z, one_minus_alpha * g.v[j].w);
-      }
-      store_row(t, b.gpred + off, d, lane);
-      store_row(g, b.gM + off, d, lane);
-    } else {
-      zero_frag(g);
-      store_row(g, b.gM + off, d, lane);
-    }
-    load_opt(g, b.gnum_o, off, d, lane);
-    store_row(g, b.gnum + off, d, lane);
-    load_opt(g, b.gden_o, off, d, lane);
-    store_row(g, b.gden + off, d, lane);
-    if (afd) {
-      load_opt(g, b.gvar_o, off, d, lane);
-      store_row(g, b.gvar + off, d, lane);
-    }
-    if (rt && lane == 0) {
-      b.gradius[row] = b.gradius_o ? b.gradius_o[row] : 0.f;
-      b.gradius_var[row] = b.gradius_var_o ? b.gradius_var_o[row] : 0.f;
-    }
+    inactive_passthrough<DCH>(b, row, lane, one_minus_alpha);
   }
 }
 
 // ---------------------------------------------------------------- o-projection backward
 template <int DCH, int RPW>
-__global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b) {
+__global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b, int fold) {
   const ic_region_args& a = b.f;
   const int r = blockIdx.y;
   if (!region_has_work(a.mask, a.S, a.R, r)) return;
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b) {
     for (int i = 0; i < RPW; ++i) {
       const int ch = row0 + i;
       if (ch < d) {  // wave-uniform
-        const float g = b.ghpre[off + ch];
+        const float g = fold ? (b.gH ? b.gH[off + ch] * a.gate[off + ch] : 0.f) : b.ghpre[off + ch];
         float gi = g;
         if (rt) {
           const float hd = wave_sum(dot_frag(wo[i], op));
@@ -218,60 +229,62 @@ __global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b) {
 }
 
 // ---------------------------------------------------------------- middle: gy + RT scalars
+// Radial-tangential (region.py:219-235): the full row g = d/d dir (already scaled by radius')
+// becomes gy = g / n + coef * y and the scalar Kalman chain of the radius is differentiated.
+// Every wave that needs gy runs this redundantly (8 KB of slab rows from L2); `writer` stores
+// the scalar outputs once per row.
 template <int DCH>
-__global__ __launch_bounds__(256) void k_region_mid_bwd(ic_region_bwd_args b, int nslab) {
+__device__ __forceinline__ void rt_gy_row(const ic_region_bwd_args& b, RowFrag<DCH>& g, int row, int r,
+                                          int nslab, int lane, bool writer) {
   const ic_region_args& a = b.f;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  const int SR = a.S * a.R;
-  if (row >= SR || !a.mask[row]) return;
-  const int d = a.d, r = row % a.R;
+  const int d = a.d, SR = a.S * a.R;
   const size_t off = (size_t)row * d;
-  RowFrag<DCH> g;
+  RowFrag<DCH> y;
+  load_row(y, a.y + off, d, lane);
+  // one lane per slab fetches its partial d/d radius' (one round trip), summed in slab order
+  float part = 0.f;
+  for (int s0 = 0; s0 < nslab; s0 += 64)
+    if (s0 + lane < nslab) part = b.slab_rt[(size_t)(s0 + lane) * SR + row];
+  const float n = a.ynorm[row];
+  const float rho = a.radius[row];
+  const float pn_p = a.rpn_param[r], on_p = a.ron_param[r];
+  const float rv = a.radius_var[row];
+  const float Grho_o = b.gradius_o ? b.gradius_o[row] : 0.f;
+  const float Grv = b.gradius_var_o ? b.gradius_var_o[row] : 0.f;
   zero_frag(g);
-  sum_slabs(g, b.slab + (size_t)row * d, (size_t)SR * d, nslab, d, lane);
-  if (a.flags & IC_F_RT) {
-    // g currently holds d/d dir (already scaled by radius'); region.py:219-235
-    RowFrag<DCH> y;
-    load_row(y, a.y + off, d, lane);
-    float g_rho_h = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) g_rho_h += b.slab_rt[(size_t)sl * SR + row];
-    const float n = a.ynorm[row];
-    const float ynrm = sqrtf(wave_sum(dot_frag(y, y)));
-    const float gdy = wave_sum(dot_frag(g, y));
-    const float rho = a.radius[row];
-    const float pn_p = a.rpn_param[r], on_p = a.ron_param[r];
-    const float pv = a.radius_var[row] + ic_noise(pn_p);
-    const float on = ic_noise(on_p);
-    const float D = pv + on + IC_EPS_DIV;
-    const float gain = pv / D;
-    const float mu = (float)0.2;
-    const float Grho = (b.gradius_o ? b.gradius_o[row] : 0.f) + g_rho_h;
-    const float Grv = b.gradius_var_o ? b.gradius_var_o[row] : 0.f;
-    const float g_gain = Grho * mu * (n - rho) - Grv * pv;
-    const float g_pv = Grv * (1.0f - gain) + g_gain * (on + IC_EPS_DIV) / (D * D);
-    const float g_on = -g_gain * pv / (D * D);
-    float g_n = Grho * mu * gain - gdy / (n * n);
-    if (!(ynrm >= IC_EPS_DIV)) g_n = 0.f;  // clamp_min blocks the gradient
-    const float coef = ynrm > 0.f ? g_n / ynrm : 0.f;
+  sum_slabs(g, b.slab + off, (size_t)SR * d, nslab, d, lane);
+  float g_rho_h = 0.f;
+  for (int sl = 0; sl < nslab; ++sl) g_rho_h += __shfl(part, sl, 64);
+  const float ynrm = sqrtf(wave_sum(dot_frag(y, y)));
+  const float gdy = wave_sum(dot_frag(g, y));
+  const float pv = rv + ic_noise(pn_p);
+  const float on = ic_noise(on_p);
+  const float D = pv + on + IC_EPS_DIV;
+  const float gain = pv / D;
+  const float mu = (float)0.2;
+  const float Grho = Grho_o + g_rho_h;
+  const float g_gain = Grho * mu * (n - rho) - Grv * pv;
+  const float g_pv = Grv * (1.0f - gain) + g_gain * (on + IC_EPS_DIV) / (D * D);
+  const float g_on = -g_gain * pv / (D * D);
+  float g_n = Grho * mu * gain - gdy / (n * n);
+  if (!(ynrm >= IC_EPS_DIV)) g_n = 0.f;  // clamp_min blocks the gradient
+  const float coef = ynrm > 0.f ? g_n / ynrm : 0.f;
 #pragma unroll
-    for (int j = 0; j < DCH; ++j) {
-      g.v[j].x = g.v[j].x / n + coef * y.v[j].x; g.v[j].y = g.v[j].y / n + coef * y.v[j].y;
-      g.v[j].z = g.v[j].z / n + coef * y.v[j].z; g.v[j].w = g.v[j].w / n + coef * y.v[j].w;
-    }
-    if (lane == 0) {
-      b.gradius[row] = Grho * (1.0f - mu * gain);
-      b.gradius_var[row] = g_pv;
-      b.g_rnoise_rows[row * 2 + 0] = g_pv * ic_noise_grad(pn_p);
-      b.g_rnoise_rows[row * 2 + 1] = g_on * ic_noise_grad(on_p);
-    }
+  for (int j = 0; j < DCH; ++j) {
+    g.v[j].x = g.v[j].x / n + coef * y.v[j].x; g.v[j].y = g.v[j].y / n + coef * y.v[j].y;
+    g.v[j].z = g.v[j].z / n + coef * y.v[j].z; g.v[j].w = g.v[j].w / n + coef * y.v[j].w;
   }
-  store_row(g, b.gy + off, d, lane);
+  if (writer && lane == 0) {
+    b.gradius[row] = Grho * (1.0f - mu * gain);
+    b.gradius_var[row] = g_pv;
+    b.g_rnoise_rows[row * 2 + 0] = g_pv * ic_noise_grad(pn_p);
+    b.g_rnoise_rows[row * 2 + 1] = g_on * ic_noise_grad(on_p);
+  }
 }
 
 // ---------------------------------------------------------------- r,k,v + state backward
 template <int DCH, int RPW>
-__global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
+__global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, int nslab) {
   const ic_region_args& a = b.f;
   const int r = blockIdx.y;
   if (!region_has_work(a.mask, a.S, a.R, r)) return;
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
       zero_frag(wr[i]); zero_frag(wk[i]); zero_frag(wv[i]);
     }
   }
-  const bool afd = a.flags & IC_F_AFD, vec = a.flags & IC_F_NOISE_VEC;
+  const bool afd = a.flags & IC_F_AFD, vec = a.flags & IC_F_NOISE_VEC, rt = a.flags & IC_F_RT;
   const int SR = a.S * a.R;
   for (int s = 0; s < a.S; ++s) {
     const int row = s * a.R + r;
@@ -302,31 +315,58 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
     const size_t off = (size_t)row * d;
     const float steps = (float)(a.dt[row] + 1);
     RowFrag<DCH> acc;
-    zero_frag(acc);
     {  // lane l < RPW owns channel row0 + l: every operand of the wave's rows in ONE batch of loads
       const int chr = row0 + (lane < RPW ? lane : 0);
       const bool valid = lane < RPW && chr < d;  // rotation pairs (even, odd lane) are valid together
       const int ch = valid ? chr : 0;            // clamp loads
       const size_t idx = off + ch;
-      // ---- recompute the forward for this channel
+      // ---- every per-channel operand is requested before the row-wide gy reduction below
       const float rd = a.raw_decay[(size_t)r * d + ch];
+      const float num_in = a.num[idx], den_in = a.den[idx];
+      const float rr = a.r_s[idx], kk = a.k_s[idx], vv = a.v_s[idx];
+      const float gno = b.gnum_o ? b.gnum_o[idx] : 0.f;
+      const float gdo = b.gden_o ? b.gden_o[idx] : 0.f;
+      float pn_p = 0.f, on_p = 0.f, var_in = 0.f, gvo = 0.f;
+      if (afd) {
+        pn_p = vec ? a.pn_param[(size_t)r * d + ch] : a.pn_param[r];
+        on_p = vec ? a.on_param[(size_t)r * d + ch] : a.on_param[r];
+        var_in = a.var[idx];
+        gvo = b.gvar_o ? b.gvar_o[idx] : 0.f;
+      }
+      // ---- gy of this channel: the o-projection's slabs, reduced here (no launch of its own)
+      float gy;
+      if (rt) {
+        rt_gy_row<DCH>(b, acc, row, r, nslab, lane, blockIdx.x == 0 && wave == 0);
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          float* p = &red[wave][256 * j + 4 * lane];
+          p[0] = acc.v[j].x; p[1] = acc.v[j].y; p[2] = acc.v[j].z; p[3] = acc.v[j].w;
+        }
+        __syncthreads();
+        gy = red[wave][ch];
+        __syncthreads();
+      } else {
+        gy = 0.f;
+        for (int s0 = 0; s0 < nslab; s0 += 8) {
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = s0 + u < nslab ? b.slab[((size_t)(s0 + u) * SR + row) * d + ch] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (s0 + u < nslab) gy += t[u];
+        }
+      }
+      zero_frag(acc);
+      // ---- recompute the forward for this channel
       const float rate = -ic_softplus(rd);
       const float ex = expf(rate * steps);
       const float lam = fmaxf(ex, IC_EPS_DIV);
-      const float num_in = a.num[idx], den_in = a.den[idx];
       const float numd = num_in * lam, dend = den_in * lam;
-      const float rr = a.r_s[idx], kk = a.k_s[idx], vv = a.v_s[idx];
       const float w = expf(fminf(kk, IC_MAX_EXP));
-      const float gy = b.gy[idx];
-      const float gno = b.gnum_o ? b.gnum_o[idx] : 0.f;
-      const float gdo = b.gden_o ? b.gden_o[idx] : 0.f;
       float g_r, g_v, g_w, g_numd, g_dend, g_lam, g_k_extra = 0.f, g_var_in = 0.f;
       float g_pn_p = 0.f, g_on_p = 0.f;
       if (afd) {
-        const float pn_p = vec ? a.pn_param[(size_t)r * d + ch] : a.pn_param[r];
-        const float on_p = vec ? a.on_param[(size_t)r * d + ch] : a.on_param[r];
         const float pn = ic_noise(pn_p), on = ic_noise(on_p);
-        const float var_in = a.var[idx];
         const float vard = var_in * (lam * lam) + pn * steps;
         const float dpe = dend + IC_EPS_DIV;
         const float prd = numd / dpe;
@@ -338,7 +378,6 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
         const float gain = fminf(fmaxf(graw, IC_EPS_DIV), 1.0f);
         const float st = prd + gain * resid;
         const float den_n = dend + w;
-        const float gvo = b.gvar_o ? b.gvar_o[idx] : 0.f;
         g_r = gy * st;
         const float g_st = gy * rr + gno * den_n;
         const float g_den_n = gno * st + gdo;
@@ -424,7 +463,7 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
         tot.v[j].z = (red[0][c + 2] + red[1][c + 2]) + (red[2][c + 2] + red[3][c + 2]);
         tot.v[j].w = (red[0][c + 3] + red[1][c + 3]) + (red[2][c + 3] + red[3][c + 3]);
       }
-      store_row(tot, b.slab + ((size_t)blockIdx.x * SR + row) * d, d, lane);
+      store_row(tot, b.slab2 + ((size_t)blockIdx.x * SR + row) * d, d, lane);
     }
     __syncthreads();
   }
@@ -432,18 +471,32 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b) {
 
 // ---------------------------------------------------------------- prologue backward
 template <int DCH>
-__global__ __launch_bounds__(256) void k_region_pro_bwd(ic_region_bwd_args b, int nslab) {
+__global__ __launch_bounds__(256) void k_region_pro_bwd(ic_region_bwd_args b, int nslab, int fold,
+                                                        float one_minus_alpha) {
   const ic_region_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   const int SR = a.S * a.R;
-  if (row >= SR || !a.mask[row]) return;
+  if (row >= SR) return;
+  if (!a.mask[row]) {
+    if (fold) inactive_passthrough<DCH>(b, row, lane, one_minus_alpha);
+    return;
+  }
   const int d = a.d, r = row % a.R, s = row / a.R;
   const size_t off = (size_t)row * d;
   const float inv_d = 1.0f / (float)d;
   RowFrag<DCH> g, t, u, w;
-  load_row(g, b.ghpre + off, d, lane);  // residual path h = x + ...
-  sum_slabs(g, b.slab + (size_t)row * d, (size_t)SR * d, nslab, d, lane);
+  if (fold) {  // hard KWTA: ghpre = gH * gate
+    load_opt(g, b.gH, off, d, lane);
+    load_row(t, a.gate + off, d, lane);
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      g.v[j].x *= t.v[j].x; g.v[j].y *= t.v[j].y; g.v[j].z *= t.v[j].z; g.v[j].w *= t.v[j].w;
+    }
+  } else {
+    load_row(g, b.ghpre + off, d, lane);  // residual path h = x + ...
+  }
+  sum_slabs(g, b.slab2 + (size_t)row * d, (size_t)SR * d, nslab, d, lane);
   load_row(t, a.x + off, d, lane);
   store_row(t, b.tape_x + off, d, lane);
   // ---- region norm: x = nw * u1 * inv1
@@ -560,7 +613,7 @@ extern "C" int ic_region_phase_bwd(const ic_region_bwd_args* b, ic_stream_t stre
                  a->x && a->u1 && a->inv_s && a->r_s && a->k_s && a->v_s && a->y && a->hpre && a->gate,
              "ic_region_phase_bwd: NULL forward pointer");
   IC_REQUIRE(b->gM && b->gnum && b->gden && b->g_norm_w_rows && b->g_raw_decay_rows && b->tape_g &&
-                 b->tape_x && b->tape_o && b->ghpre && b->gy && b->slab,
+                 b->tape_x && b->tape_o && b->ghpre && b->slab && b->slab2 && b->slab != b->slab2,
              "ic_region_phase_bwd: NULL gradient/workspace pointer");
   IC_REQUIRE(!(a->flags & IC_F_PRED) || b->gpred, "ic_region_phase_bwd: gpred is NULL");
   IC_REQUIRE(!(a->flags & IC_F_NORM_IN) || (a->norm_in_w && b->g_norm_in_rows),
@@ -578,28 +631,24 @@ extern "C" int ic_region_phase_bwd(const ic_region_bwd_args* b, ic_stream_t stre
   const int nslab = ic_bwd_nslab(a->d);
   const dim3 blk(256), grow(ic_ceil_div(rows, 4)), gmat(nslab, a->R);
   const float oma = (float)(1.0 - a->pred_alpha);
-  if (a->d <= 256) {
-    constexpr int DCH = 1;
-    IC_TIMED(IC_KID_region_fin_bwd, st, hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma));
-    IC_TIMED(IC_KID_region_out_bwd, st, hipLaunchKernelGGL((k_region_out_bwd<DCH, 8>), gmat, blk, 0, st, *b));
-    IC_TIMED(IC_KID_region_mid_bwd, st, hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab));
-    IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 8>), gmat, blk, 0, st, *b));
-    IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab));
-  } else if (a->d <= 512) {
-    constexpr int DCH = 2;
-    IC_TIMED(IC_KID_region_fin_bwd, st, hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma));
-    IC_TIMED(IC_KID_region_out_bwd, st, hipLaunchKernelGGL((k_region_out_bwd<DCH, 2>), gmat, blk, 0, st, *b));
-    IC_TIMED(IC_KID_region_mid_bwd, st, hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab));
-    IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 2>), gmat, blk, 0, st, *b));
-    IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab));
-  } else {
-    constexpr int DCH = 4;
-    IC_TIMED(IC_KID_region_fin_bwd, st, hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma));
-    IC_TIMED(IC_KID_region_out_bwd, st, hipLaunchKernelGGL((k_region_out_bwd<DCH, 2>), gmat, blk, 0, st, *b));
-    IC_TIMED(IC_KID_region_mid_bwd, st, hipLaunchKernelGGL(k_region_mid_bwd<DCH>, grow, blk, 0, st, *b, nslab));
-    IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, 2>), gmat, blk, 0, st, *b));
-    IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab));
-  }
+  const bool soft = (a->flags & IC_F_KWTA_SOFT) && !(a->flags & IC_F_NOKWTA) && a->kwta_k > 0;
+  const int fold = soft ? 0 : 1;
+#define IC_REGION_BWD(DCH_, RPW_)                                                                                            \
+  do {                                                                                                                       \
+    constexpr int DCH = DCH_;                                                                                                \
+    if (!fold)                                                                                                               \
+      IC_TIMED(IC_KID_region_fin_bwd, st, hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma));             \
+    IC_TIMED(IC_KID_region_out_bwd, st, hipLaunchKernelGGL((k_region_out_bwd<DCH, RPW_>), gmat, blk, 0, st, *b, fold));      \
+    IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, RPW_>), gmat, blk, 0, st, *b, nslab));     \
+    IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab, fold, oma));  \
+  } while (0)
+  if (a->d <= 256)
+    IC_REGION_BWD(1, 8);
+  else if (a->d <= 512)
+    IC_REGION_BWD(2, 2);
+  else
+    IC_REGION_BWD(4, 2);
+#undef IC_REGION_BWD
   IC_LAUNCH_CHECK("ic_region_phase_bwd");
   return IC_OK;
 }

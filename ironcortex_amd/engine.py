@@ -204,7 +204,7 @@ class LoopEngine:
         R, d, E = m.R, m.d, max(m.router.E, 1)
         ns = ops.bwd_nslab(d)
         z = lambda *s: torch.zeros(*s, device=device)
-        ws = {"gM": z(2, R, d), "ghpre": z(R, d), "gy": z(R, d), "slab": z(ns, R, d), "slab_rt": z(ns, R),
+        ws = {"gM": z(2, R, d), "ghpre": z(R, d), "slab2": z(ns, R, d), "slab": z(ns, R, d), "slab_rt": z(ns, R),
               "gH_tmp": z(2, R, d), "gHd": z(2, R, d), "rslab": z(ns, 2, E, d), "slab_q": z(ns, 2, R, d)}
         for side in ("a", "b"):
             for k in ("gnum", "gden", "gvar", "gpred"):
@@ -691,7 +691,7 @@ class LoopEngine:
         b = new("ic_region_bwd_args")
         b.f = ops._region_args(bank.spec, P, 1, 0.0, s.kwta_k, flags, s.kwta_temp)
         b.f.sensor = s.sensor.data_ptr()
-        b.gM, b.ghpre, b.gy, b.slab, b.slab_rt = WP["gM"], WP["ghpre"], WP["gy"], WP["slab"], WP["slab_rt"]
+        b.gM, b.ghpre, b.slab2, b.slab, b.slab_rt = WP["gM"], WP["ghpre"], WP["slab2"], WP["slab"], WP["slab_rt"]
         rb = new("ic_router_bwd_args")
         rspec = ops.RouterSpec(R, d, E, router.nW, prec)
         if E > 0:

@@ -249,7 +249,7 @@ class RegionPhaseFn(torch.autograd.Function):
         nslab = bwd_nslab(d)
         out = dict(gM=_e(M, S, R, d), gnum=_e(M, S, R, d), gden=_e(M, S, R, d),
                    g_norm_w_rows=_z(M, S, R, d), g_raw_decay_rows=_z(M, S, R, d),
-                   ghpre=_e(M, S, R, d), gy=_e(M, S, R, d), slab=_e(M, nslab, S, R, d))
+                   ghpre=_e(M, S, R, d), slab2=_e(M, nslab, S, R, d), slab=_e(M, nslab, S, R, d))
         if use_pred:
             out["gpred"] = _e(M, S, R, d)
         if norm_in:
