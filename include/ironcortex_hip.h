@@ -44,7 +44,12 @@ enum {
   IC_F_KWTA_SOFT = 1 << 4,  /* soft KWTA during warm-up (region.py:244-246) */
   IC_F_NOISE_VEC = 1 << 5,  /* afd_noise_mode == "vector" (region.py:63-68) */
   IC_F_NORM_IN = 1 << 6,    /* apply shared norm_in + sensor add (model.py:198-204) */
-  IC_F_NEED_GRAD = 1 << 7   /* write the saved-for-backward buffers */
+  IC_F_NEED_GRAD = 1 << 7,  /* write the saved-for-backward buffers */
+  IC_F_CHAIN = 1 << 8       /* forward only: the S "streams" are S consecutive steps of ONE state stream
+                               (the branches of an outer iteration, model.py:388-392, which the
+                               reference runs one after another on the same cells): the input state
+                               arrays and `sensor` hold one stream ([1,R,..]), stream s > 0 starts
+                               from the state stream s-1 left, outputs are [S,R,..].  S <= 64. */
 };
 
 /* router flags */

@@ -17,19 +17,11 @@ namespace {
 // x = RMSNorm_r( RMSNorm_in(M[r] (+sensor)) + pred )   (region.py:173-177, model.py:198-204)
 // All operand rows are requested before the first reduction.
 template <int DCH>
-__device__ __forceinline__ void prologue_row(const ic_region_args& a, int row, int lane, RowFrag<DCH>& u1,
-                                             RowFrag<DCH>& x, float& inv0, float& inv1) {
-  const int s = row / a.R, r = row % a.R;
-  const int d = a.d;
+__device__ __forceinline__ void prologue_math(RowFrag<DCH>& u, const RowFrag<DCH>& sv, const RowFrag<DCH>& win,
+                                              const RowFrag<DCH>& p, const RowFrag<DCH>& w, bool io, bool norm_in,
+                                              bool pred, int d, RowFrag<DCH>& u1, RowFrag<DCH>& x, float& inv0,
+                                              float& inv1) {
   const float inv_d = 1.0f / (float)d;
-  const bool norm_in = a.flags & IC_F_NORM_IN, pred = a.flags & IC_F_PRED;
-  const bool io = norm_in && a.sensor && (r == a.sensor_idx || r == a.motor_idx);
-  RowFrag<DCH> u, sv, win, p, w;
-  load_row(u, a.M + (size_t)row * d, d, lane);
-  if (io) load_row(sv, a.sensor + (size_t)s * d, d, lane);
-  if (norm_in) load_row(win, a.norm_in_w, d, lane);
-  if (pred) load_row(p, a.pred + (size_t)row * d, d, lane);
-  load_row(w, a.norm_w + (size_t)r * d, d, lane);
   inv0 = 1.0f;
   if (norm_in) {
     if (io) {
@@ -65,6 +57,62 @@ __device__ __forceinline__ void prologue_row(const ic_region_args& a, int row, i
 }
 
 template <int DCH>
+__device__ __forceinline__ void prologue_row(const ic_region_args& a, int row, int lane, RowFrag<DCH>& u1,
+                                             RowFrag<DCH>& x, float& inv0, float& inv1) {
+  const int s = row / a.R, r = row % a.R;
+  const int d = a.d;
+  const bool norm_in = a.flags & IC_F_NORM_IN, pred = a.flags & IC_F_PRED;
+  const bool io = norm_in && a.sensor && (r == a.sensor_idx || r == a.motor_idx);
+  RowFrag<DCH> u, sv, win, p, w;
+  load_row(u, a.M + (size_t)row * d, d, lane);
+  if (io) load_row(sv, a.sensor + (size_t)s * d, d, lane);
+  if (norm_in) load_row(win, a.norm_in_w, d, lane);
+  if (pred) load_row(p, a.pred + (size_t)row * d, d, lane);
+  load_row(w, a.norm_w + (size_t)r * d, d, lane);
+  prologue_math(u, sv, win, p, w, io, norm_in, pred, d, u1, x, inv0, inv1);
+}
+
+// IC_F_CHAIN: the trace and dt of region r as they stand when stream s starts, given the last
+// stream before s that had the region active (prev, -1: none).  Streams in between were
+// inactive: each is one trace EMA step on its own message row (region.py:140-146) and dt+1.
+template <int DCH>
+__device__ __forceinline__ void chain_prologue(const ic_region_args& a, int r, int s, int prev, int lane,
+                                               float one_minus_alpha, RowFrag<DCH>& u1, RowFrag<DCH>& x,
+                                               float& inv0, float& inv1, float& steps) {
+  const int d = a.d;
+  const bool norm_in = a.flags & IC_F_NORM_IN, pred = a.flags & IC_F_PRED;
+  const bool io = norm_in && a.sensor && (r == a.sensor_idx || r == a.motor_idx);
+  RowFrag<DCH> u, sv, win, p, w;
+  load_row(u, a.M + ((size_t)s * a.R + r) * d, d, lane);
+  if (io) load_row(sv, a.sensor, d, lane);
+  if (norm_in) load_row(win, a.norm_in_w, d, lane);
+  load_row(w, a.norm_w + (size_t)r * d, d, lane);
+  int dtv = 0;
+  zero_frag(p);
+  if (prev < 0) {
+    if (pred) load_row(p, a.pred + (size_t)r * d, d, lane);
+    dtv = a.dt[r];
+  }
+  const float al = (float)a.pred_alpha;
+  for (int q = prev + 1; q < s; ++q) {
+    if (pred) {
+      RowFrag<DCH> m;
+      load_row(m, a.M + ((size_t)q * a.R + r) * d, d, lane);
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        p.v[j].x = al * p.v[j].x + one_minus_alpha * m.v[j].x;
+        p.v[j].y = al * p.v[j].y + one_minus_alpha * m.v[j].y;
+        p.v[j].z = al * p.v[j].z + one_minus_alpha * m.v[j].z;
+        p.v[j].w = al * p.v[j].w + one_minus_alpha * m.v[j].w;
+      }
+    }
+    dtv += 1;
+  }
+  steps = (float)(dtv + 1);
+  prologue_math(u, sv, win, p, w, io, norm_in, pred, d, u1, x, inv0, inv1);
+}
+
+template <int DCH>
 __global__ __launch_bounds__(256) void k_region_pro(ic_region_args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
@@ -93,8 +141,11 @@ __device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int 
 // all loaded up front so every wave keeps 6*PP independent 1 KiB row requests in flight.
 // FUSE: the prologue is recomputed by every wave instead of being a launch of its own (few
 // streams: the extra row loads are L2 hits, the saved launch is ~6 us).
-template <int DCH, int PP, bool FUSE>
-__global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
+// CHAIN (IC_F_CHAIN, needs FUSE): the streams are consecutive steps of one state stream; the state
+// a stream starts from is what the previous active stream of this launch computed (registers) or,
+// before the first one, the input state [1,R,..].
+template <int DCH, int PP, bool FUSE, bool CHAIN>
+__global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a, float one_minus_alpha) {
   const int r = blockIdx.y;
   if (!region_has_work(a.mask, a.S, a.R, r)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -149,12 +200,16 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
     float steps;
     float num[PP], den[PP], var[PP];
   };
-  auto request = [&](int s, Ops& o) {
+  auto request = [&](int s, int prev, Ops& o) {
     const int row = s * a.R + r;
     if (FUSE) {
       RowFrag<DCH> u1;
       float inv0, inv1;
-      prologue_row(a, row, lane, u1, o.xv, inv0, inv1);
+      if (CHAIN) {
+        chain_prologue(a, r, s, prev, lane, one_minus_alpha, u1, o.xv, inv0, inv1, o.steps);
+      } else {
+        prologue_row(a, row, lane, u1, o.xv, inv0, inv1);
+      }
       if (blockIdx.x == 0 && wave == 0) {  // saved for the backward / the output projection
         store_row(u1, a.u1 + (size_t)row * d, d, lane);
         store_row(o.xv, a.x + (size_t)row * d, d, lane);
@@ -166,12 +221,14 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
     } else {
       load_row(o.xv, a.x + (size_t)row * d, d, lane);
     }
-    o.steps = (float)(a.dt[row] + 1);
+    if (!CHAIN) o.steps = (float)(a.dt[row] + 1);
+    if (CHAIN && prev >= 0) return;  // state: handed over in registers after the previous stream
+    const int srow = CHAIN ? r : row;
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
       o.num[p] = o.den[p] = o.var[p] = 0.f;
       if (lane < 2 && ok[p]) {
-        const size_t idx = (size_t)row * d + row0 + 2 * p + lane;
+        const size_t idx = (size_t)srow * d + row0 + 2 * p + lane;
         o.num[p] = a.num[idx];
         o.den[p] = a.den[idx];
         if (afd) o.var[p] = a.var[idx];
@@ -185,15 +242,17 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
     Ops cur, nxt;
     int s_cur = sc + __ffsll((long long)act) - 1;
     act &= act - 1;
-    request(s_cur, cur);
+    request(s_cur, -1, cur);
     while (s_cur >= 0) {
       const int s_nxt = act ? sc + __ffsll((long long)act) - 1 : -1;
       act &= act - 1;
-      if (s_nxt >= 0) request(s_nxt, nxt);
+      if (s_nxt >= 0) request(s_nxt, s_cur, nxt);
       const int row = s_cur * a.R + r;
       const float steps = cur.steps;
+      float nn[PP], dn[PP], vn[PP];
 #pragma unroll
       for (int p = 0; p < PP; ++p) {
+        nn[p] = dn[p] = vn[p] = 0.f;
         const float pr0 = wave_sum(dot_frag(wr[2 * p], cur.xv)), pr1 = wave_sum(dot_frag(wr[2 * p + 1], cur.xv));
         const float pk0 = wave_sum(dot_frag(wk[2 * p], cur.xv)), pk1 = wave_sum(dot_frag(wk[2 * p + 1], cur.xv));
         const float pv0 = wave_sum(dot_frag(wv[2 * p], cur.xv)), pv1 = wave_sum(dot_frag(wv[2 * p + 1], cur.xv));
@@ -217,7 +276,8 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
             const float st = prd + gain * resid;
             den_n = dend + w;
             num_n = st * den_n;
-            a.var_o[idx] = (1.0f - gain) * vard;
+            vn[p] = (1.0f - gain) * vard;
+            a.var_o[idx] = vn[p];
             a.sterm[idx] = (resid * resid) * (1.0f / (vard + obs));
             yv = rr * st;
           } else {  // region.py:214-216
@@ -231,6 +291,16 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a) {
           a.r_s[idx] = rr;
           a.k_s[idx] = kk;
           a.v_s[idx] = vv;
+          nn[p] = num_n;
+          dn[p] = den_n;
+        }
+      }
+      if (CHAIN && s_nxt >= 0) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+          nxt.num[p] = nn[p];
+          nxt.den[p] = dn[p];
+          nxt.var[p] = vn[p];
         }
       }
       cur = nxt;
@@ -256,8 +326,10 @@ __global__ __launch_bounds__(256) void k_region_out(ic_region_args a) {
     if (row0 + i < d) load_row(wo[i], Wo + (size_t)(row0 + i) * d, d, lane);
     else zero_frag(wo[i]);
   }
-  const bool rt = a.flags & IC_F_RT;
+  const bool rt = a.flags & IC_F_RT, chain = a.flags & IC_F_CHAIN;
   const float rpn = rt ? ic_noise(a.rpn_param[r]) : 0.f, ron = rt ? ic_noise(a.ron_param[r]) : 0.f;
+  // IC_F_CHAIN: the radius state is carried from one active stream to the next in registers
+  float c_rad = (rt && chain) ? a.radius[r] : 0.f, c_rvar = (rt && chain) ? a.radius_var[r] : 0.f;
   struct Ops {
     RowFrag<DCH> yv;
     float xres[PP];
@@ -267,7 +339,7 @@ __global__ __launch_bounds__(256) void k_region_out(ic_region_args a) {
     const int row = s * a.R + r;
     load_row(o.yv, a.y + (size_t)row * d, d, lane);
     o.rad = o.rvar = 0.f;
-    if (rt) {
+    if (rt && !chain) {
       o.rad = a.radius[row];
       o.rvar = a.radius_var[row];
     }
@@ -298,20 +370,23 @@ __global__ __launch_bounds__(256) void k_region_out(ic_region_args a) {
         for (int j = 0; j < DCH; ++j) {
           yv.v[j].x /= nrm; yv.v[j].y /= nrm; yv.v[j].z /= nrm; yv.v[j].w /= nrm;
         }
-        const float rad = cur.rad;
-        const float pvar = cur.rvar + rpn;
+        const float rad = chain ? c_rad : cur.rad;
+        const float pvar = (chain ? c_rvar : cur.rvar) + rpn;
         const float resid = nrm - rad;
         const float gain = pvar / (pvar + ron + IC_EPS_DIV);
         const float upd = rad + gain * resid;
         const float mu = (float)0.2, omu = (float)(1.0 - 0.2);
         scale = omu * rad + mu * upd;
+        c_rad = scale;
+        c_rvar = (1.0f - gain) * pvar;
         if (blockIdx.x == 0 && wave == 0) {
-          if (a.last_dir) store_row(yv, a.last_dir + (size_t)row * d, d, lane);
+          const int trow = chain ? r : row;  // telemetry of the one state stream
+          if (a.last_dir) store_row(yv, a.last_dir + (size_t)trow * d, d, lane);
           if (lane == 0) {
             a.radius_o[row] = scale;
-            a.radius_var_o[row] = (1.0f - gain) * pvar;
+            a.radius_var_o[row] = c_rvar;
             a.ynorm[row] = nrm;
-            if (a.last_norm) a.last_norm[row] = nrm;
+            if (a.last_norm) a.last_norm[trow] = nrm;
           }
         }
       }
@@ -405,6 +480,101 @@ __global__ __launch_bounds__(256) void k_region_fin(ic_region_args a, float one_
   }
 }
 
+// IC_F_CHAIN finish: one wave per REGION walks the streams in order and carries the trace, dt,
+// surprise EMA and (for the pass-through copies of inactive streams) the source of the state rows.
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_fin_chain(ic_region_args a, float one_minus_alpha) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.R) return;
+  const int d = a.d;
+  const bool afd = a.flags & IC_F_AFD, rt = a.flags & IC_F_RT, pred = a.flags & IC_F_PRED;
+  RowFrag<DCH> z, p;
+  zero_frag(z);
+  zero_frag(p);
+  if (pred) load_row(p, a.pred + (size_t)r * d, d, lane);
+  int dtv = a.dt[r];
+  float surp = afd ? a.surprise[r] : 0.f;
+  float rad = rt ? a.radius[r] : 0.f, rvar = rt ? a.radius_var[r] : 0.f;
+  // rows written by an EARLIER launch that hold the current state (never this wave's own copies)
+  const float* num_src = a.num + (size_t)r * d;
+  const float* den_src = a.den + (size_t)r * d;
+  const float* var_src = afd ? a.var + (size_t)r * d : nullptr;
+  const float al = (float)a.pred_alpha;
+  for (int s = 0; s < a.S; ++s) {
+    const int row = s * a.R + r;
+    const size_t off = (size_t)row * d;
+    if (a.mask[row]) {
+      RowFrag<DCH> h, out, g;
+      load_row(h, a.hpre + off, d, lane);
+      if (a.flags & IC_F_NOKWTA) {
+        out = h;
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) g.v[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+      } else {
+        kwta_row(h, out, g, d, a.kwta_k, (a.flags & IC_F_KWTA_SOFT) != 0, a.kwta_temp);
+      }
+      store_row(out, a.H + off, d, lane);
+      store_row(g, a.gate + off, d, lane);
+      if (pred) {
+        store_row(z, a.pred_o + off, d, lane);
+        p = z;
+      }
+      if (afd) {
+        RowFrag<DCH> st;
+        load_row(st, a.sterm + off, d, lane);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) sum += (st.v[j].x + st.v[j].y) + (st.v[j].z + st.v[j].w);
+        sum = wave_sum(sum);
+        surp = (float)0.99 * surp + (float)(1.0 - 0.99) * sum;
+        if (lane == 0) a.surprise_o[row] = surp;
+        var_src = a.var_o + off;
+      }
+      dtv = 0;
+      if (lane == 0) a.dt_o[row] = 0;
+      num_src = a.num_o + off;
+      den_src = a.den_o + off;
+      if (rt) {
+        rad = a.radius_o[row];
+        rvar = a.radius_var_o[row];
+      }
+    } else {
+      store_row(z, a.H + off, d, lane);
+      RowFrag<DCH> t;
+      if (pred) {
+        RowFrag<DCH> m;
+        load_row(m, a.M + off, d, lane);
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          p.v[j].x = al * p.v[j].x + one_minus_alpha * m.v[j].x;
+          p.v[j].y = al * p.v[j].y + one_minus_alpha * m.v[j].y;
+          p.v[j].z = al * p.v[j].z + one_minus_alpha * m.v[j].z;
+          p.v[j].w = al * p.v[j].w + one_minus_alpha * m.v[j].w;
+        }
+        store_row(p, a.pred_o + off, d, lane);
+      }
+      load_row(t, num_src, d, lane);
+      store_row(t, a.num_o + off, d, lane);
+      load_row(t, den_src, d, lane);
+      store_row(t, a.den_o + off, d, lane);
+      if (afd) {
+        load_row(t, var_src, d, lane);
+        store_row(t, a.var_o + off, d, lane);
+      }
+      dtv += 1;
+      if (lane == 0) {
+        a.dt_o[row] = dtv;
+        if (afd) a.surprise_o[row] = surp;
+        if (rt) {
+          a.radius_o[row] = rad;
+          a.radius_var_o[row] = rvar;
+        }
+      }
+    }
+  }
+}
+
 template <int DCH>
 __global__ __launch_bounds__(256) void k_kwta_rows(const float* x, float* y, float* gate, int rows,
                                                    int d, int k, int soft, float temp) {
@@ -459,17 +629,25 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
   if (a->d > 256 && rpb > 16) rpb = 16;  // register budget at DCH >= 2
   const dim3 gmat(ic_ceil_div(a->d, rpb), a->R);
   const float oma = (float)(1.0 - a->pred_alpha);
-  const bool fuse = a->S <= 2 && a->R <= 64;  // prologue inside rkv (measured a loss at R = 512)
+  const bool chain = a->flags & IC_F_CHAIN;
+  IC_REQUIRE(!chain || a->S <= 64, "ic_region_phase_fwd: IC_F_CHAIN needs S <= 64 (S=%d)", a->S);
+  const bool fuse = chain || (a->S <= 2 && a->R <= 64);  // prologue inside rkv (measured a loss at R = 512)
 #define IC_FWD_LAUNCH(PP)                                                                                   \
   IC_DISPATCH_DCH(a->d, {                                                                                   \
-    if (fuse) {                                                                                             \
-      IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, true>), gmat, blk, 0, st, *a));  \
+    if (chain) {                                                                                            \
+      IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, true, true>), gmat, blk, 0, st, *a, oma));  \
+    } else if (fuse) {                                                                                      \
+      IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, true, false>), gmat, blk, 0, st, *a, oma));  \
     } else {                                                                                                \
       IC_TIMED(IC_KID_region_pro, st, hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a));         \
-      IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, false>), gmat, blk, 0, st, *a)); \
+      IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, false, false>), gmat, blk, 0, st, *a, oma)); \
     }                                                                                                       \
     IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL((k_region_out<DCH, PP>), gmat, blk, 0, st, *a));     \
-    IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma));      \
+    if (chain) {                                                                                            \
+      IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin_chain<DCH>, dim3(ic_ceil_div(a->R, 4)), blk, 0, st, *a, oma)); \
+    } else {                                                                                                \
+      IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma));    \
+    }                                                                                                       \
   })
   if (rpb == 8) IC_FWD_LAUNCH(1);
   else if (rpb == 16) IC_FWD_LAUNCH(2);

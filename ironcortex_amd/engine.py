@@ -347,9 +347,13 @@ class LoopEngine:
             m.counters["inner_steps"] += nb
             return list(range(i, i + nb))
 
-        def region(i: int, stream) -> None:
-            """Region phase of step i (state chained from the previously executed step)."""
+        chain_flag = ENUMS["IC_F_CHAIN"]
+
+        def region(i: int, stream, n: int = 1) -> None:
+            """Region phase of the n consecutive steps i..i+n-1 (state chained from the previously
+            executed step; n > 1: IC_F_CHAIN, the steps are the streams of one launch sequence)."""
             a = i0 + i
+            fa.S, fa.flags = n, (flags | chain_flag if n > 1 else flags)
             fa.step_pos, fa.M, fa.mask = step_pos_l[i], CP["M"] + a * CS["M"], CP["mask"] + a * CS["mask"]
             fa.num, fa.den, fa.dt = state["num"], state["den"], state["dt"]
             fa.var, fa.surprise = state["var"], state["surprise"]
@@ -358,7 +362,7 @@ class LoopEngine:
             for k, ko in out_names:
                 p = CP[ko] + a * CS[ko]
                 setattr(fa, ko, p)
-                state[k] = p
+                state[k] = p + (n - 1) * CS[ko]
             for k in saved:
                 setattr(fa, k, CP[k] + a * CS[k])
             rc = p_fwd(fa_ref, stream)
@@ -615,8 +619,7 @@ class LoopEngine:
             pars = [branches[b][1] for b in range(B_br)]   # IndexError for B_br > 2, as in the reference
             sls = [branches[b][0] for b in range(B_br)]
             ids = front(pars, k, u_mean, burst, st)          # gate + router of every branch
-            for cur in ids:                                  # region phases share the state chain
-                region(cur, st)
+            region(ids[0], st, len(ids))                     # the branches share the state chain
             if not heads(ids, pars, sls):
                 raise RuntimeError("LoopEngine: branch inputs are not equally spaced (B_br > 2 is not supported)")
             verify(ids[0], len(ids))
