@@ -266,6 +266,12 @@ int ic_gate_select(const ic_gate_args* a, ic_stream_t stream);
  * computes the scores of its stream itself). */
 int ic_gate_fwd(const ic_gate_args* a, ic_stream_t stream);
 
+/* Gate (new mask) and router (messages from the previous states and mask) of the same inner step as
+ * ONE launch sequence: the two read the same inputs and are independent (model.py:254-262 calls
+ * them back to back).  Same results as ic_gate_fwd followed by ic_router_fwd; g and a must agree
+ * in S, R, d.  Falls back to the two calls for R > 64 or E == 0. */
+int ic_front_fwd(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream);
+
 /* ------------------------------------------------------------------ primitives
  * KWTA (utils.py:38-60) on `rows` rows of width d: threshold = k-th largest |x|,
  * ties keep extra units.  gate receives the multiplier (for the backward). */
@@ -385,6 +391,9 @@ int ic_prof_enable(int on);
 /* Bracket only kernel id `kid` (-1 = all): two event records per launch cost more than some of
  * these kernels run, so a throughput measurement times just the kernel it reports on. */
 int ic_prof_select(int kid);
+/* Bracket 1 launch in n of those that qualify (n = 1: every one): a sample of a kernel's launches
+ * gives the same average at a fraction of the event cost. */
+int ic_prof_stride(int n);
 int ic_prof_kernel_count(void);
 const char* ic_prof_kernel_name(int kid);
 int ic_prof_read(int kid, int64_t* launches, double* total_ms);

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "ic_common.h"
+#include "ic_gate.h"
 
 // ---------------------------------------------------------------- error plumbing
 static thread_local char g_err[512] = "";
@@ -59,47 +60,6 @@ __global__ __launch_bounds__(256) void k_gate_scores(ic_gate_args a) {
   }
 }
 
-// Stable descending rank by counting, then the greedy suppression walk on one lane (R <= 1024,
-// the walk stops after k selections).  sc[] holds the stream's scores; all threads call.
-__device__ __forceinline__ void gate_select_body(const ic_gate_args& a, int s, const float* sc, int* order,
-                                                 uint8_t* supp) {
-  const int R = a.R;
-  for (int i = threadIdx.x; i < R; i += blockDim.x) {
-    supp[i] = 0;
-    a.mask[s * R + i] = 0;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < R; i += blockDim.x) {
-    const float v = sc[i];
-    int rank = 0;
-    for (int j = 0; j < R; ++j) {
-      const float u = sc[j];
-      rank += (u > v) || (u == v && j < i);
-    }
-    order[rank] = i;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint8_t* mask = a.mask + s * R;
-    int k = a.k_total > 0 ? a.k_total : 0;
-    if (a.force_io) {  // gate.py:80-84
-      mask[a.sensor_idx] = 1;
-      mask[a.motor_idx] = 1;
-      k = k - 2 > 0 ? k - 2 : 0;
-    }
-    int count = 0;
-    for (int p = 0; p < R; ++p) {  // utils.py:115-123
-      const int i = order[p];
-      if (supp[i]) continue;
-      mask[i] = 1;
-      ++count;
-      if (count >= k) break;
-      supp[i] = 1;
-      for (int q = a.nbr_off[i]; q < a.nbr_off[i + 1]; ++q) supp[a.nbr[q]] = 1;
-    }
-  }
-}
-
 // One workgroup per stream.
 __global__ __launch_bounds__(256) void k_gate_select(ic_gate_args a) {
   __shared__ float sc[1024];
@@ -111,40 +71,13 @@ __global__ __launch_bounds__(256) void k_gate_select(ic_gate_args a) {
   gate_select_body(a, s, sc, order, supp);
 }
 
-// Scores and selection in ONE launch for small region counts: the workgroup of a stream reads
-// its R rows itself (R*d*4 bytes: 10 KB at R=10, one CU is enough) and goes straight on to the
-// walk.  Saves a launch per inner step where launches, not bytes, are the cost.
+// Scores and selection in ONE launch for small region counts (body: ic_gate.h).
 template <int DCH>
 __global__ __launch_bounds__(256) void k_gate_fused(ic_gate_args a) {
   __shared__ float sc[1024];
   __shared__ int order[1024];
   __shared__ uint8_t supp[1024];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int s = blockIdx.x;
-  for (int r = wave; r < a.R; r += 4) {
-    const int row = s * a.R + r;
-    RowFrag<DCH> h;
-    load_row(h, a.H + (size_t)s * (a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d) + (size_t)r * a.d, a.d, lane);
-    float part = 0.f;
-#pragma unroll
-    for (int j = 0; j < DCH; ++j)
-      part += (fabsf(h.v[j].x) + fabsf(h.v[j].y)) + (fabsf(h.v[j].z) + fabsf(h.v[j].w));
-    const float content = wave_sum(part) / (float)a.d;
-    if (lane == 0) {
-      const float focus =
-          (a.focus_any && a.focus_any[s] && (r == a.sensor_idx || r == a.motor_idx)) ? 1.0f : 0.0f;
-      float v = a.w1 * content;
-      v = v + a.w2 * a.gain_ema[r];
-      v = v + a.w3 * focus;
-      v = v - a.w4 * a.homeo[r];
-      v = v + a.t5;
-      v = v + a.t6;
-      a.scores[row] = v;
-      sc[r] = v;
-    }
-  }
-  __syncthreads();
-  gate_select_body(a, s, sc, order, supp);
+  gate_fused_body<DCH>(a, blockIdx.x, sc, order, supp);
 }
 
 template <int DCH>

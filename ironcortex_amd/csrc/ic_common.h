@@ -192,11 +192,12 @@ enum IcKid {
 // Optional live kernel timing with HIP events on the launch stream (ic_prof_* in the header).
 extern bool g_ic_prof_on;
 extern int g_ic_prof_only;
+bool ic_prof_sampled();  // every launch, or 1 in ic_prof_stride() of the selected kernel's
 void ic_prof_begin(int kid, hipStream_t st);
 void ic_prof_end(int kid, hipStream_t st);
 #define IC_TIMED(kid, st, ...)                                  \
   do {                                                          \
-    const bool t__ = g_ic_prof_on && (g_ic_prof_only < 0 || g_ic_prof_only == (kid)); \
+    const bool t__ = g_ic_prof_on && (g_ic_prof_only < 0 || g_ic_prof_only == (kid)) && ic_prof_sampled(); \
     if (t__) ic_prof_begin(kid, (hipStream_t)(st));             \
     __VA_ARGS__;                                                \
     if (t__) ic_prof_end(kid, (hipStream_t)(st));               \

@@ -8,6 +8,10 @@
 
 bool g_ic_prof_on = false;
 int g_ic_prof_only = -1;  // -1: every kernel; otherwise only this kernel id is bracketed
+static int g_stride = 1;  // bracket 1 launch in g_stride (of the launches that qualify)
+static unsigned g_tick = 0;
+
+bool ic_prof_sampled() { return g_stride <= 1 || (g_tick++ % (unsigned)g_stride) == 0; }
 
 namespace {
 struct Pair {
@@ -46,6 +50,12 @@ extern "C" int ic_prof_enable(int on) {
 extern "C" int ic_prof_select(int kid) {
   IC_REQUIRE(kid >= -1 && kid < IC_KID_COUNT, "ic_prof_select: kid=%d", kid);
   g_ic_prof_only = kid;
+  return IC_OK;
+}
+extern "C" int ic_prof_stride(int n) {
+  IC_REQUIRE(n >= 1, "ic_prof_stride: n=%d", n);
+  g_stride = n;
+  g_tick = 0;
   return IC_OK;
 }
 extern "C" int ic_prof_kernel_count(void) { return IC_KID_COUNT; }

@@ -6,6 +6,7 @@
 // walked in the reference's index_add_ order.  Precision-routed path: edge GEMVs (messages,
 // keys, queries) then a wave-per-destination softmax combine.
 #include "ic_common.h"
+#include "ic_gate.h"
 
 namespace {
 
@@ -34,9 +35,8 @@ __device__ __forceinline__ bool prev_on(const ic_router_args& a, int s, int r) {
 // accumulated edge by edge in index order.  R=512, k=32, d=256: 26 us at S=1 (1.9 TB/s), 76 us at
 // S=8 (4.1 TB/s), 278 us at S=64 (2.7 TB/s).
 template <int DCH>
-__global__ __launch_bounds__(256) void k_router_fwd_ms(ic_router_args a) {
+__device__ __forceinline__ void router_fwd_ms_body(const ic_router_args& a, const int r) {
   __shared__ float acc[64][kRowsPerBlock];
-  const int r = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
   const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
@@ -85,16 +85,20 @@ __global__ __launch_bounds__(256) void k_router_fwd_ms(ic_router_args a) {
   }
 }
 
-// ---------------------------------------------------------------- precision: edge GEMVs
-// blockIdx.y < E: message + key of edge e;  blockIdx.y >= E: query of region y-E.
 template <int DCH>
-__global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
+__global__ __launch_bounds__(256) void k_router_fwd_ms(ic_router_args a) {
+  router_fwd_ms_body<DCH>(a, blockIdx.y);
+}
+
+// ---------------------------------------------------------------- precision: edge GEMVs
+// y < E: message + key of edge e;  y >= E: query of region y-E.
+template <int DCH>
+__device__ __forceinline__ void router_edge_body(const ic_router_args& a, const int y) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
   const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
   if (row0 >= d) return;
   const size_t dd = (size_t)d * d;
-  const int y = blockIdx.y;
   if (y < a.E) {
     const int e = y, src = a.src[e];
     bool any = false;
@@ -139,6 +143,31 @@ __global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
       if (lane < 2) a.q[((size_t)s * a.R + r) * d + row0 + lane] = lane ? v1 : v0;
     }
   }
+}
+
+template <int DCH>
+__global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
+  router_edge_body<DCH>(a, blockIdx.y);
+}
+
+// ---------------------------------------------------------------- gate + router in one launch
+// The gate (scores + selection of the NEW mask, gate.py:54-87) and the router (messages from the
+// PREVIOUS states and mask) read the same inputs and do not depend on each other: the first
+// g.S workgroup rows of the grid run the gate (one workgroup per stream), the rest the router.
+template <int DCH, bool PRECISION>
+__global__ __launch_bounds__(256) void k_front(ic_router_args a, ic_gate_args g) {
+  if ((int)blockIdx.y < g.S) {
+    if (blockIdx.x != 0) return;
+    __shared__ float sc[1024];
+    __shared__ int order[1024];
+    __shared__ uint8_t supp[1024];
+    gate_fused_body<DCH>(g, blockIdx.y, sc, order, supp);
+    return;
+  }
+  if (PRECISION)
+    router_edge_body<DCH>(a, (int)blockIdx.y - g.S);
+  else
+    router_fwd_ms_body<DCH>(a, (int)blockIdx.y - g.S);
 }
 
 // ---------------------------------------------------------------- precision: combine (wave per (s,dst))
@@ -744,6 +773,36 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
     IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL(k_router_fwd_ms<DCH>, dim3(nsl, a->R), dim3(256), 0, st, *a)); });
   }
   IC_LAUNCH_CHECK("ic_router_fwd");
+  return IC_OK;
+}
+
+extern "C" int ic_front_fwd(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream) {
+  IC_REQUIRE(g != nullptr && a != nullptr, "ic_front_fwd: NULL args");
+  if (g->R > 64 || a->E == 0) {  // big maps: the gate's scores want the whole chip (ic_gate_fwd)
+    int rc = ic_gate_fwd(g, stream);
+    return rc ? rc : ic_router_fwd(a, stream);
+  }
+  int rc = check_router(a, "ic_front_fwd");
+  if (rc) return rc;
+  IC_REQUIRE(g->S == a->S && g->R == a->R && g->d == a->d, "ic_front_fwd: gate (S=%d,R=%d,d=%d) and router (S=%d,R=%d,d=%d) disagree",
+             g->S, g->R, g->d, a->S, a->R, a->d);
+  IC_REQUIRE(g->scores && g->H && g->gain_ema && g->homeo && g->mask && g->nbr_off && g->nbr, "ic_front_fwd: NULL gate pointer");
+  IC_REQUIRE(!g->force_io || (g->sensor_idx >= 0 && g->sensor_idx < g->R && g->motor_idx >= 0 && g->motor_idx < g->R),
+             "ic_front_fwd: io indices out of range");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsl = ic_ceil_div(a->d, kRowsPerBlock);
+  if (a->flags & IC_RF_PRECISION) {
+    IC_DISPATCH_DCH(a->d, {
+      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_front<DCH, true>), dim3(nsl, g->S + a->E + a->R), dim3(256), 0, st, *a, *g));
+    });
+    const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
+    if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
+    else if (a->d <= 512) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<2>, gcomb, dim3(256), 0, st, *a));
+    else IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<4>, gcomb, dim3(256), 0, st, *a));
+  } else {
+    IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_front<DCH, false>), dim3(nsl, g->S + a->R), dim3(256), 0, st, *a, *g)); });
+  }
+  IC_LAUNCH_CHECK("ic_front_fwd");
   return IC_OK;
 }
 

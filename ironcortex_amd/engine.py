@@ -129,6 +129,9 @@ class LoopEngine:
         self._unit_log = []
         self._in_cache = None
         self._pass = None  # accumulators of the backward pass in flight
+        self._sess = None  # C structs shared by the loops between two reset()s
+        self._hs_ok = False
+        self._fa_buf = None
         model._coord.register(self._begin_pass, self._finish_pass)
 
     # ------------------------------------------------------------------ applicability
@@ -150,6 +153,8 @@ class LoopEngine:
         tensors are views of the last loop's final slot until now; copy them out first."""
         self._rescue_state()
         self.flush_units()
+        self._sess = None
+        self._hs_ok = False  # parameters may have moved since: _heads_setup checks every pointer again
         if self._arena is not None:
             self._arena.reset()
 
@@ -241,14 +246,19 @@ class LoopEngine:
         ebias_c = ebias.detach().contiguous()
         norm_in_w = m.norm_in.weight
         tables = router._edge_tables(m.reg_coords)
-        rP, bP = router._params(), bank.params()
         kw_k, kw_soft, kw_temp = bank.kwta_now()
         flags = bank._flags(kw_soft, bank.cells[0].disable_kwta, True)
         # the branches of an outer iteration go through gate / router / heads as ONE launch each
         # (streams of the same call), so the loop's inputs are kept once per branch
         nbr_ = 1 if cfg.train_deterministic_inner_loop else max(1, cfg.B_br)
-        focus_any = (focus_map.any().to(_U8).reshape(1) if focus_map.numel() > 0
-                     else torch.ones(1, dtype=_U8, device=dev)).repeat(nbr_)
+        fab = self._fa_buf
+        if fab is None or fab.device != dev or fab.numel() != nbr_:
+            fab = self._fa_buf = torch.ones(nbr_, dtype=_U8, device=dev)
+        focus_any = fab  # stream-ordered reuse: earlier loops' launches have read it by the time it changes
+        if focus_map.numel() > 0:
+            focus_any.copy_(focus_map.any())
+        else:
+            focus_any.fill_(1)
         ikey = (H_prev.data_ptr(), H_prev._version, reg_mask_prev.data_ptr(), reg_mask_prev._version, nbr_)
         if self._in_cache is not None and self._in_cache[0] == ikey:
             H0, mask0 = self._in_cache[1], self._in_cache[2]  # same (unmodified) tensors as the last loop
@@ -256,22 +266,30 @@ class LoopEngine:
             H0 = H_prev.detach().float().reshape(1, R, d).repeat(nbr_, 1, 1)
             mask0 = reg_mask_prev.to(_U8).reshape(1, R).repeat(nbr_, 1)
             self._in_cache = (ikey, H0, mask0, H_prev, reg_mask_prev)
-        off, nbr = gate._tables(dev)
-
-        # ---- structs: everything static is set once per loop
-        ga = new("ic_gate_args", S=1, R=R, d=d, sensor_idx=m.io_idxs["sensor"], motor_idx=m.io_idxs["motor"],
-                 force_io=1, w1=gate.w1, w2=gate.w2, w3=gate.w3, w4=gate.w4, gain_ema=gate.gain_ema,
-                 homeo=gate.homeo, focus_any=focus_any, nbr_off=off, nbr=nbr)
-        rspec = ops.RouterSpec(R, d, E, router.nW, router.enable_precision_routed_messages)
-        ra = ops._router_args(rspec, tables, rP, 1)
+        # ---- structs: everything static is set once per session (the loops between two reset()s
+        # that share parameters, tables and schedule), the per-loop pointers are patched below
+        skey = (dev, bank.flat.flat.data_ptr(), router._flat.flat.data_ptr(), norm_in_w.data_ptr(),
+                gate.gain_ema.data_ptr(), gate.homeo.data_ptr(), id(tables), kw_k, flags, kw_temp, nbr_)
+        sess = self._sess
+        if sess is None or sess[0] != skey:
+            rP, bP = router._params(), bank.params()
+            off, nbr = gate._tables(dev)
+            ga = new("ic_gate_args", S=1, R=R, d=d, sensor_idx=m.io_idxs["sensor"], motor_idx=m.io_idxs["motor"],
+                     force_io=1, w1=gate.w1, w2=gate.w2, w3=gate.w3, w4=gate.w4, gain_ema=gate.gain_ema,
+                     homeo=gate.homeo, nbr_off=off, nbr=nbr)
+            rspec = ops.RouterSpec(R, d, E, router.nW, router.enable_precision_routed_messages)
+            ra = ops._router_args(rspec, tables, rP, 1)
+            P = dict(bP)
+            P["norm_in_w"] = norm_in_w
+            fa = ops._region_args(bank.spec, P, 1, 0.0, kw_k, flags, kw_temp)
+            sess = self._sess = (skey, rP, bP, off, nbr, ga, ra, fa, rspec, P)
+        _, rP, bP, off, nbr, ga, ra, fa, rspec, P = sess
+        ga.focus_any = focus_any.data_ptr()
         ra.ebias = ebias_c.data_ptr()
-        P = dict(bP)
-        P["norm_in_w"] = norm_in_w
-        fa = ops._region_args(bank.spec, P, 1, 0.0, kw_k, flags, kw_temp)
         fa.sensor = sens_c.data_ptr()
         fa.last_dir, fa.last_norm = bank.last_dir.data_ptr(), bank.last_norm.data_ptr()
         prec, afd, rt_, use_pred = rspec.precision, bank.afd, bank.rt, bank.use_pred
-        g_fwd = L.ic_gate_fwd
+        g_fwd, f_fwd = L.ic_gate_fwd, L.ic_front_fwd
         r_fwd, p_fwd = L.ic_router_fwd, L.ic_region_phase_fwd
         ga_ref, ra_ref, fa_ref = ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(fa)
         w5, w6 = gate.w5, gate.w6
@@ -329,17 +347,18 @@ class LoopEngine:
             ga.t5, ga.t6 = w5 * float(gate.value_bias), w6 * float(u_mean)
             ga.k_total = max(0, cfg.k_active + burst)
             ga.scores, ga.mask = CP["scores"] + a * CS["scores"], CP["mask"] + a * CS["mask"]
-            rc = g_fwd(ga_ref, stream)
-            if rc:
-                check(rc, "ic_gate")
-            if E > 0:
+            if E > 0:  # gate and router read the same inputs: one launch sequence
                 ra.S, ra.H, ra.mask_prev, ra.M = nb, h_in, mk_in, CP["M"] + a * CS["M"]
                 ra.H_sstride, ra.mask_sstride = hs, ms
                 for k in rsaved:
                     setattr(ra, k, CP[k] + a * CS[k])
-                rc = r_fwd(ra_ref, stream)
+                rc = f_fwd(ga_ref, ra_ref, stream)
                 if rc:
-                    check(rc, "ic_router_fwd")
+                    check(rc, "ic_front_fwd")
+            else:
+                rc = g_fwd(ga_ref, stream)
+                if rc:
+                    check(rc, "ic_gate")
             # (E == 0: M stays at the zeros the arena was created with)
             for par in pars:
                 parent.append(par)
@@ -378,10 +397,12 @@ class LoopEngine:
         H_of = lambda i: Hf[i0 + i] if i >= 0 else H0[0]
         mask_of = lambda i: Mf[i0 + i] if i >= 0 else mask0[0]
         with torch.no_grad():
-            best, last_step, traces = self._drive((step, front, region), in_ptrs, H_of, K_inner, dev, chunk, i0)
+            best, last_step, traces = self._drive((step, front, region), in_ptrs, H_of, K_inner, dev, chunk, i0,
+                                                  trace_views=bool(m._logits_detached and grad))
         n = len(parent)
-        last_logits = (chunk.fields["logits"][i0 + last_step].clone() if last_step >= 0
-                       else torch.zeros(m.V, device=dev))
+        last_logits = (chunk.fields["logits"][i0 + last_step] if last_step >= 0 else torch.zeros(m.V, device=dev))
+        if not (m._logits_detached and grad):  # train_step stacks the loops' logits before the arena is reset
+            last_logits = last_logits.clone()
         if best >= 0:
             m.work.slots = chunk.fields["slots"][i0 + best]
 
@@ -450,6 +471,10 @@ class LoopEngine:
         parameters move (device change, deepcopy, load into new storage)."""
         m = self.model
         hf = m._heads_flat
+        nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
+        hs = getattr(self, "_hs", None)
+        if hs is not None and self._hs_ok and hs["key"][:3] == (dev, nb, hf.flat.data_ptr()):
+            return hs  # checked in full since the last reset()
         hf.reflat()  # no-op while every facet / region-head Parameter still views the arena
         mods = [m.lm_head.gate]
         if m.plan is not None:
@@ -457,9 +482,8 @@ class LoopEngine:
                      m.critic.mlp.net[0], m.critic.mlp.net[2]]
         if m.verify is not None:
             mods += [m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]]
-        nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
         key = (dev, nb, hf.flat.data_ptr()) + tuple(p.data_ptr() for l in mods for p in (l.weight, l.bias))
-        hs = getattr(self, "_hs", None)
+        self._hs_ok = True
         if hs is not None and hs["key"] == key:
             return hs
         R, d, V, Kf = m.R, m.d, m.V, m.lm_head.Kf
@@ -513,7 +537,7 @@ class LoopEngine:
         self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods, nb=nb)
         return self._hs
 
-    def _drive(self, steps, in_ptrs, H_of, K_inner, dev, chunk, i0):
+    def _drive(self, steps, in_ptrs, H_of, K_inner, dev, chunk, i0, trace_views=False):
         """The control flow of reference model.py:329-460 over step ids, heads on the HIP library.
         Within an outer iteration the branches are chained only through the region state: their
         gate, router, heads and verifier run as one launch sequence with one stream per branch;
@@ -522,7 +546,8 @@ class LoopEngine:
         m = self.model
         cfg, gate = m.cfg, m.gate
         L, st = lib(), stream_handle()
-        keep = (lambda t: t) if (m._logits_detached and torch.is_grad_enabled()) else (lambda t: t.clone())
+        # train_step never reads the traces after its backward: views of the arena (valid until reset())
+        keep = (lambda t: t) if trace_views else (lambda t: t.clone())
         hs = self._heads_setup(dev)
         ha, ver, steer, sa, P, ls, nb = hs["ha"], hs["ver"], hs["steer"], hs["sa"], hs["P"], hs["buf"]["ls"], hs["nb"]
         ha_ref, sa_ref = ctypes.byref(ha), ctypes.byref(sa)

@@ -151,9 +151,10 @@ def prof_enable(on: bool) -> None:
     lib().ic_prof_enable(ctypes.c_int(1 if on else 0))
 
 
-def prof_select(name: str = "") -> None:
-    """Time only the named kernel ("" = all)."""
+def prof_select(name: str = "", stride: int = 1) -> None:
+    """Time only the named kernel ("" = all), one launch in `stride`."""
     l = lib()
+    check(l.ic_prof_stride(ctypes.c_int(max(1, stride))), "ic_prof_stride")
     kid = -1
     if name:
         names = [l.ic_prof_kernel_name(ctypes.c_int(k)).decode() for k in range(l.ic_prof_kernel_count())]

@@ -20,3 +20,8 @@ for key in ("tottime", "cumulative"):
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
     print(s.getvalue()[:9000])
+s = io.StringIO()
+st = pstats.Stats(pr, stream=s)
+for pat in ("clone", "zeros_like", "copy_", "'zeros'", "'empty'", "fill_", "'stack'", "'cat'", "index_add", "'to'"):
+    st.print_callers(pat)
+print(s.getvalue()[:14000])

@@ -188,7 +188,7 @@ def test_strided_streams_equal_separate_calls():
     ebias = router._edge_bias(prod.reg_coords).detach().contiguous()
     E = router.E
 
-    def run(S, Hptr, mptr, hs, ms):
+    def run(S, Hptr, mptr, hs, ms, fused=False):
         out = dict(scores=torch.zeros(S, R, device=DEV), mask=torch.zeros(S, R, dtype=torch.uint8, device=DEV),
                    M=torch.zeros(S, R, d, device=DEV), msg=torch.zeros(S, E, d, device=DEV),
                    keyv=torch.zeros(S, E, d, device=DEV), q=torch.zeros(S, R, d, device=DEV), wgt=torch.zeros(S, E, device=DEV))
@@ -197,18 +197,24 @@ def test_strided_streams_equal_separate_calls():
                      w3=0.5, w4=0.2, t5=0.1, t6=0.05, gain_ema=gate.gain_ema, homeo=gate.homeo, focus_any=fa,
                      nbr_off=off, nbr=nbr, scores=out["scores"], mask=out["mask"])
         ga.H, ga.H_sstride = Hptr, hs
-        hip.check(L.ic_gate_fwd(ctypes.byref(ga), st), "gate")
         spec = ops.RouterSpec(R, d, E, router.nW, True)
         ra = ops._router_args(spec, tables, router._params(), S)
         ra.ebias, ra.H, ra.mask_prev, ra.H_sstride, ra.mask_sstride = ebias.data_ptr(), Hptr, mptr, hs, ms
         for k in ("M", "msg", "keyv", "q", "wgt"):
             hip.set_field(ra, k, out[k])
-        hip.check(L.ic_router_fwd(ctypes.byref(ra), st), "router")
+        if fused:  # gate riding in the router's launch
+            hip.check(L.ic_front_fwd(ctypes.byref(ga), ctypes.byref(ra), st), "front")
+        else:
+            hip.check(L.ic_gate_fwd(ctypes.byref(ga), st), "gate")
+            hip.check(L.ic_router_fwd(ctypes.byref(ra), st), "router")
         torch.cuda.synchronize()
         return out
 
     # streams in reversed slot order: stream 0 reads H2[1], stream 1 reads H2[0]
     both = run(2, H2[1].data_ptr(), mp2[1].data_ptr(), -R * d, -R)
+    front = run(2, H2[1].data_ptr(), mp2[1].data_ptr(), -R * d, -R, fused=True)
+    for k in both:
+        assert torch.equal(front[k], both[k]), ("ic_front_fwd != ic_gate_fwd + ic_router_fwd", k)
     for s_, src in ((0, 1), (1, 0)):
         one = run(1, H2[src].data_ptr(), mp2[src].data_ptr(), 0, 0)
         for k in one:
