@@ -147,6 +147,12 @@ typedef struct ic_region_bwd_args {
   float* slab2;   /* [nslab,S,R,d] partial W_{r,k,v}^T g (must not alias slab: the kernel that
                      writes slab2 is still reading slab) */
   float* slab_rt; /* [nslab,S,R] RT only: partial d/d radius' */
+  int32_t sk;     /* spread-out streams: stream s lives at stream index s*sk of EVERY [S,R,..] / [nslab,S,R,..]
+                     array of this call (f.sensor and gsens rows excepted: gsens is spread, f.sensor is
+                     [S,d]), which are then sized for S*sk streams.  0/1 = contiguous.  Lets the same
+                     step of several independent loops, recorded sk step slots apart, run as the
+                     streams of one launch (the reference detaches the state between the samples of a
+                     batch, model.py:482-487, so their backward passes are independent). */
 } ic_region_bwd_args;
 
 int ic_region_phase_bwd(const ic_region_bwd_args* a, ic_stream_t stream);
@@ -219,6 +225,12 @@ typedef struct ic_router_bwd_args {
   float* slab;   /* [nslab,S,E,d], nslab = ic_bwd_nslab(d) */
   float* slab_q; /* [nslab,S,R,d] precision only */
   int64_t gH_sstride; /* elements between consecutive streams' gH blocks; 0 = contiguous (R*d) */
+  int32_t sk;         /* spread-out streams as in ic_region_bwd_args.sk: applies to every per-stream array
+                         of this call except f.H, f.mask_prev and gH */
+  const int32_t* in_slot; /* [S] or NULL.  When set, stream s reads its input states / previous mask
+                         from block in_slot[s] of f.H / f.mask_prev (R*d floats / R bytes per block) and
+                         writes gH to block in_slot[s] of gH (the strides above are ignored);
+                         in_slot[s] < 0: the stream is skipped (tape_eact / tape_qact rows cleared). */
 } ic_router_bwd_args;
 int ic_router_bwd(const ic_router_bwd_args* a, ic_stream_t stream);
 

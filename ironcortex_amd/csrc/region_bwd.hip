@@ -13,10 +13,22 @@
 
 namespace {
 
-__device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int R, int r) {
+// Streams may be spread out (ic_region_bwd_args.sk): stream s lives at stream index s*sk of every
+// [S,R,..] array of the call.
+__device__ __forceinline__ int stream_step(const ic_region_bwd_args& b) { return b.sk > 1 ? b.sk : 1; }
+__device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int R, int r, int sk) {
   for (int s = 0; s < S; ++s)
-    if (mask[s * R + r]) return true;
+    if (mask[(size_t)s * sk * R + r]) return true;
   return false;
+}
+// wave-per-row kernels: local row index -> (stream, region, row in the spread-out arrays)
+__device__ __forceinline__ bool spread_row(const ic_region_bwd_args& b, int lrow, int& s, int& r, int& row) {
+  const ic_region_args& a = b.f;
+  if (lrow >= a.S * a.R) return false;
+  s = lrow / a.R;
+  r = lrow % a.R;
+  row = s * stream_step(b) * a.R + r;
+  return true;
 }
 
 template <int DCH>
@@ -69,8 +81,8 @@ template <int DCH>
 __global__ __launch_bounds__(256) void k_region_fin_bwd(ic_region_bwd_args b, float one_minus_alpha) {
   const ic_region_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= a.S * a.R) return;
+  int s_, r_, row;
+  if (!spread_row(b, blockIdx.x * 4 + wave, s_, r_, row)) return;
   const int d = a.d;
   const size_t off = (size_t)row * d;
   if (a.mask[row]) {
@@ -150,7 +162,8 @@ template <int DCH, int RPW>
 __global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b, int fold) {
   const ic_region_args& a = b.f;
   const int r = blockIdx.y;
-  if (!region_has_work(a.mask, a.S, a.R, r)) return;
+  const int sk = stream_step(b);
+  if (!region_has_work(a.mask, a.S, a.R, r, sk)) return;
   __shared__ float red[4][DCH * 256 + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
@@ -166,9 +179,9 @@ __global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b, in
       zero_frag(wo[i]);
   }
   const bool rt = a.flags & IC_F_RT;
-  const int SR = a.S * a.R;
+  const int SR = a.S * sk * a.R;
   for (int s = 0; s < a.S; ++s) {
-    const int row = s * a.R + r;
+    const int row = s * sk * a.R + r;
     if (!a.mask[row]) continue;  // block-uniform
     const size_t off = (size_t)row * d;
     RowFrag<DCH> op, acc;
@@ -237,7 +250,7 @@ template <int DCH>
 __device__ __forceinline__ void rt_gy_row(const ic_region_bwd_args& b, RowFrag<DCH>& g, int row, int r,
                                           int nslab, int lane, bool writer) {
   const ic_region_args& a = b.f;
-  const int d = a.d, SR = a.S * a.R;
+  const int d = a.d, SR = a.S * stream_step(b) * a.R;
   const size_t off = (size_t)row * d;
   RowFrag<DCH> y;
   load_row(y, a.y + off, d, lane);
@@ -287,7 +300,8 @@ template <int DCH, int RPW>
 __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, int nslab) {
   const ic_region_args& a = b.f;
   const int r = blockIdx.y;
-  if (!region_has_work(a.mask, a.S, a.R, r)) return;
+  const int sk = stream_step(b);
+  if (!region_has_work(a.mask, a.S, a.R, r, sk)) return;
   __shared__ float red[4][DCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
@@ -308,9 +322,9 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, in
     }
   }
   const bool afd = a.flags & IC_F_AFD, vec = a.flags & IC_F_NOISE_VEC, rt = a.flags & IC_F_RT;
-  const int SR = a.S * a.R;
+  const int SR = a.S * sk * a.R;
   for (int s = 0; s < a.S; ++s) {
-    const int row = s * a.R + r;
+    const int row = s * sk * a.R + r;
     if (!a.mask[row]) continue;  // block-uniform
     const size_t off = (size_t)row * d;
     const float steps = (float)(a.dt[row] + 1);
@@ -475,14 +489,15 @@ __global__ __launch_bounds__(256) void k_region_pro_bwd(ic_region_bwd_args b, in
                                                         float one_minus_alpha) {
   const ic_region_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  const int SR = a.S * a.R;
-  if (row >= SR) return;
+  int s, r, row;
+  if (!spread_row(b, blockIdx.x * 4 + wave, s, r, row)) return;
+  const int sk = stream_step(b);
+  const int SR = a.S * sk * a.R;
   if (!a.mask[row]) {
     if (fold) inactive_passthrough<DCH>(b, row, lane, one_minus_alpha);
     return;
   }
-  const int d = a.d, r = row % a.R, s = row / a.R;
+  const int d = a.d;
   const size_t off = (size_t)row * d;
   const float inv_d = 1.0f / (float)d;
   RowFrag<DCH> g, t, u, w;
@@ -548,8 +563,8 @@ __global__ __launch_bounds__(256) void k_region_pro_bwd(ic_region_bwd_args b, in
                            g.v[j].z * inv0 - u.v[j].z * k3, g.v[j].w * inv0 - u.v[j].w * k3);
     }
     if (io && b.gsens) {
-      if (r == a.sensor_idx) store_row(g, b.gsens + ((size_t)s * 2 + 0) * d, d, lane);
-      else store_row(g, b.gsens + ((size_t)s * 2 + 1) * d, d, lane);
+      if (r == a.sensor_idx) store_row(g, b.gsens + ((size_t)s * sk * 2 + 0) * d, d, lane);
+      else store_row(g, b.gsens + ((size_t)s * sk * 2 + 1) * d, d, lane);
     }
   }
   store_row(g, b.gM + off, d, lane);

@@ -321,6 +321,22 @@ __global__ __launch_bounds__(256) void k_router_combine(ic_router_args a) {
   store_row(acc, a.M + (size_t)row * d, d, lane);
 }
 
+// ---------------------------------------------------------------- backward: stream addressing
+// sk: stream s lives at stream index s*sk of the per-stream arrays; in_slot: where the stream's
+// input block is (negative: the stream takes no part in this call).
+__device__ __forceinline__ int stream_step(const ic_router_bwd_args& b) { return b.sk > 1 ? b.sk : 1; }
+__device__ __forceinline__ bool stream_live(const ic_router_bwd_args& b, int s) {
+  return !b.in_slot || b.in_slot[s] >= 0;
+}
+__device__ __forceinline__ const float* h_row(const ic_router_bwd_args& b, int s, int r) {
+  if (b.in_slot) return b.f.H + ((size_t)b.in_slot[s] * b.f.R + r) * b.f.d;
+  return h_row(b.f, s, r);
+}
+__device__ __forceinline__ bool prev_on(const ic_router_bwd_args& b, int s, int r) {
+  if (b.in_slot) return b.in_slot[s] >= 0 && b.f.mask_prev[(size_t)b.in_slot[s] * b.f.R + r] != 0;
+  return prev_on(b.f, s, r);
+}
+
 // ---------------------------------------------------------------- backward: per-destination stage
 // Produces, for every active edge, the gradient w.r.t. the biased message (tape_gmsg), and in
 // precision mode the key/query gradients and the direct d/dH_dst term.
@@ -329,21 +345,29 @@ template <int DCH>
 __global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_args b) {
   const ic_router_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= a.S * a.R) return;
-  const int d = a.d, s = row / a.R, r = row % a.R;
+  const int lrow = blockIdx.x * 4 + wave;
+  if (lrow >= a.S * a.R) return;
+  const int d = a.d, s = lrow / a.R, r = lrow % a.R;
+  const int vs = s * stream_step(b), row = vs * a.R + r;
   const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
   const bool prec = a.flags & IC_RF_PRECISION;
+  if (!stream_live(b, s)) {
+    if (lane == 0) {
+      for (int e = e0; e < e1; ++e) b.tape_eact[(size_t)vs * a.E + e] = 0;
+      if (prec) b.tape_qact[row] = 0;
+    }
+    return;
+  }
   RowFrag<DCH> G, t;
   load_row(G, b.gM + (size_t)row * d, d, lane);
-  load_row(t, h_row(a, s, r), d, lane);
+  load_row(t, h_row(b, s, r), d, lane);
   store_row(t, b.tape_H + (size_t)row * d, d, lane);
   bool any = false;
   for (int e = e0; e < e1; ++e) {
-    const bool act = prev_on(a, s, a.src[e]);
+    const bool act = prev_on(b, s, a.src[e]);
     any |= act;
-    if (lane == 0) b.tape_eact[(size_t)s * a.E + e] = act ? 1 : 0;
-    if (act && !prec) store_row(G, b.tape_gmsg + ((size_t)s * a.E + e) * d, d, lane);
+    if (lane == 0) b.tape_eact[(size_t)vs * a.E + e] = act ? 1 : 0;
+    if (act && !prec) store_row(G, b.tape_gmsg + ((size_t)vs * a.E + e) * d, d, lane);
   }
   if (!prec) return;
   if (lane == 0) b.tape_qact[row] = any ? 1 : 0;
@@ -359,17 +383,17 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_ar
     for (int e = e0; e < e1; ++e) {
       const int i = e - e0;
       gw[i] = 0.f;
-      const float w = a.wgt[(size_t)s * a.E + e];
-      if (!prev_on(a, s, a.src[e])) continue;
-      load_row(m, a.msg + ((size_t)s * a.E + e) * d, d, lane);
+      const float w = a.wgt[(size_t)vs * a.E + e];
+      if (!prev_on(b, s, a.src[e])) continue;
+      load_row(m, a.msg + ((size_t)vs * a.E + e) * d, d, lane);
       gw[i] = wave_sum(dot_frag(G, m));
       inner += w * gw[i];
     }
     for (int e = e0; e < e1; ++e) {
       const int i = e - e0;
-      if (!prev_on(a, s, a.src[e])) continue;
-      const size_t eo = ((size_t)s * a.E + e) * d;
-      const float w = a.wgt[(size_t)s * a.E + e];
+      if (!prev_on(b, s, a.src[e])) continue;
+      const size_t eo = ((size_t)vs * a.E + e) * d;
+      const float w = a.wgt[(size_t)vs * a.E + e];
       const float g_lw = w * (gw[i] - inner);
       load_row(m, a.msg + eo, d, lane);
       load_row(k, a.keyv + eo, d, lane);
@@ -421,20 +445,28 @@ template <int DCH>
 __global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
   const ic_router_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= a.S * a.R) return;
-  const int d = a.d, s = row / a.R, r = row % a.R;
+  const int lrow = blockIdx.x * 4 + wave;
+  if (lrow >= a.S * a.R) return;
+  const int d = a.d, s = lrow / a.R, r = lrow % a.R;
+  const int vs = s * stream_step(b), row = vs * a.R + r;
   const int e0 = a.dst_off[r], deg = a.dst_off[r + 1] - e0;  // <= 8, checked on the host
   const bool prec = a.flags & IC_RF_PRECISION;
+  if (!stream_live(b, s)) {
+    if (lane == 0) {
+      for (int i = 0; i < deg; ++i) b.tape_eact[(size_t)vs * a.E + e0 + i] = 0;
+      if (prec) b.tape_qact[row] = 0;
+    }
+    return;
+  }
   RowFrag<DCH> G, t;
   load_row(G, b.gM + (size_t)row * d, d, lane);
-  load_row(t, h_row(a, s, r), d, lane);
+  load_row(t, h_row(b, s, r), d, lane);
   // activity of the incoming edges: wave-uniform loads, all requested together
   bool act[8];
   bool any = false;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    act[i] = i < deg && prev_on(a, s, a.src[e0 + (i < deg ? i : 0)]);
+    act[i] = i < deg && prev_on(b, s, a.src[e0 + (i < deg ? i : 0)]);
     any |= act[i];
   }
   store_row(t, b.tape_H + (size_t)row * d, d, lane);
@@ -442,8 +474,8 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
   for (int i = 0; i < 8; ++i) {
     if (i < deg) {
       const int e = e0 + i;
-      if (lane == 0) b.tape_eact[(size_t)s * a.E + e] = act[i] ? 1 : 0;
-      if (act[i] && !prec) store_row(G, b.tape_gmsg + ((size_t)s * a.E + e) * d, d, lane);
+      if (lane == 0) b.tape_eact[(size_t)vs * a.E + e] = act[i] ? 1 : 0;
+      if (act[i] && !prec) store_row(G, b.tape_gmsg + ((size_t)vs * a.E + e) * d, d, lane);
     }
   }
   if (!prec) return;
@@ -461,8 +493,8 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
       w[i] = 0.f;
       if (act[i]) {
         const int e = e0 + i;
-        const size_t eo = ((size_t)s * a.E + e) * d;
-        w[i] = a.wgt[(size_t)s * a.E + e];
+        const size_t eo = ((size_t)vs * a.E + e) * d;
+        w[i] = a.wgt[(size_t)vs * a.E + e];
         load_row(m[i], a.msg + eo, d, lane);
         load_row(k[i], a.keyv + eo, d, lane);
         load_row(P[i], a.raw_P + (size_t)a.widx[e] * d, d, lane);
@@ -482,7 +514,7 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (!act[i]) continue;
-      const size_t eo = ((size_t)s * a.E + e0 + i) * d;
+      const size_t eo = ((size_t)vs * a.E + e0 + i) * d;
       const float g_lw = w[i] * (gw[i] - inner);
       // recompute the un-clamped mahalanobis term
       float part = 0.f;
@@ -542,9 +574,10 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   const int e = y, r = y - a.E;
   const int src = is_q ? r : a.src[e];
   // block-uniform activity test
+  const int sk = stream_step(b);
   bool any = false;
   for (int s = 0; s < a.S; ++s)
-    any |= is_q ? (b.tape_qact[s * a.R + r] != 0) : (prev_on(a, s, src));
+    any |= is_q ? (b.tape_qact[(size_t)s * sk * a.R + r] != 0) : (prev_on(b, s, src));
   if (!any) return;
   const float* W = is_q ? a.query_W + (size_t)r * dd : a.W + (size_t)a.widx[e] * dd;
   const float* K = (!is_q && prec) ? a.key_W + (size_t)a.widx[e] * dd : nullptr;
@@ -561,16 +594,17 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
     }
   }
   const float bias = is_q ? 1.0f : a.ebias[e];
-  const int SE = a.S * a.E, SR = a.S * a.R;
+  const int SE = a.S * sk * a.E, SR = a.S * sk * a.R;
   for (int s = 0; s < a.S; ++s) {
-    const bool act = is_q ? (b.tape_qact[s * a.R + r] != 0) : (prev_on(a, s, src));
+    const int vs = s * sk;
+    const bool act = is_q ? (b.tape_qact[(size_t)vs * a.R + r] != 0) : (prev_on(b, s, src));
     if (!act) continue;  // block-uniform
     RowFrag<DCH> h, acc;
     zero_frag(acc);
     float part_b = 0.f;
-    float* gvec = is_q ? b.tape_gq + ((size_t)s * a.R + r) * d : b.tape_gmsg + ((size_t)s * a.E + e) * d;
-    const float* gkey = K ? b.tape_gkey + ((size_t)s * a.E + e) * d : nullptr;
-    if (!is_q) load_row(h, h_row(a, s, src), d, lane);
+    float* gvec = is_q ? b.tape_gq + ((size_t)vs * a.R + r) * d : b.tape_gmsg + ((size_t)vs * a.E + e) * d;
+    const float* gkey = K ? b.tape_gkey + ((size_t)vs * a.E + e) * d : nullptr;
+    if (!is_q) load_row(h, h_row(b, s, src), d, lane);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int ch = row0 + i;
@@ -605,12 +639,12 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
         tot.v[j].w = (red[0][c + 3] + red[1][c + 3]) + (red[2][c + 3] + red[3][c + 3]);
       }
       if (is_q) {
-        store_row(tot, b.slab_q + ((size_t)blockIdx.x * SR + s * a.R + r) * d, d, lane);
+        store_row(tot, b.slab_q + ((size_t)blockIdx.x * SR + vs * a.R + r) * d, d, lane);
       } else {
-        store_row(tot, b.slab + ((size_t)blockIdx.x * SE + s * a.E + e) * d, d, lane);
+        store_row(tot, b.slab + ((size_t)blockIdx.x * SE + vs * a.E + e) * d, d, lane);
         if (lane == 0) {
           const int q = DCH * 256;
-          b.g_ebias_part[(size_t)blockIdx.x * SE + s * a.E + e] =
+          b.g_ebias_part[(size_t)blockIdx.x * SE + vs * a.E + e] =
               (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
         }
       }
@@ -624,24 +658,28 @@ template <int DCH>
 __global__ __launch_bounds__(256) void k_router_gather_bwd(ic_router_bwd_args b, int nslab) {
   const ic_router_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= a.S * a.R) return;
-  const int d = a.d, s = row / a.R, r = row % a.R;
-  const int SE = a.S * a.E, SR = a.S * a.R;
+  const int lrow = blockIdx.x * 4 + wave;
+  if (lrow >= a.S * a.R) return;
+  const int d = a.d, s = lrow / a.R, r = lrow % a.R;
+  const int vs = s * stream_step(b), row = vs * a.R + r;
+  const int SE = a.S * stream_step(b) * a.E, SR = a.S * stream_step(b) * a.R;
   const bool prec = a.flags & IC_RF_PRECISION;
+  if (!stream_live(b, s)) return;
   RowFrag<DCH> g;
   zero_frag(g);
   if (prec) {
     load_row(g, b.gHd + (size_t)row * d, d, lane);
     if (b.tape_qact[row]) sum_slabs(g, b.slab_q + (size_t)row * d, (size_t)SR * d, nslab, d, lane);
   }
-  if (prev_on(a, s, r)) {
+  if (prev_on(b, s, r)) {
     for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
       const int e = b.src_edges[i];
-      sum_slabs(g, b.slab + ((size_t)s * a.E + e) * d, (size_t)SE * d, nslab, d, lane);
+      sum_slabs(g, b.slab + ((size_t)vs * a.E + e) * d, (size_t)SE * d, nslab, d, lane);
     }
   }
-  store_row(g, b.gH + (int64_t)s * (b.gH_sstride ? b.gH_sstride : (int64_t)a.R * d) + (size_t)r * d, d, lane);
+  float* out = b.in_slot ? b.gH + ((size_t)b.in_slot[s] * a.R + r) * d
+                         : b.gH + (int64_t)s * (b.gH_sstride ? b.gH_sstride : (int64_t)a.R * d) + (size_t)r * d;
+  store_row(g, out, d, lane);
 }
 
 // ---------------------------------------------------------------- deferred edge weight gradient
