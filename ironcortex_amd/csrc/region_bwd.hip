@@ -16,8 +16,11 @@ namespace {
 // Streams may be spread out (ic_region_bwd_args.sk): stream s lives at stream index s*sk of every
 // [S,R,..] array of the call.
 __device__ __forceinline__ int stream_step(const ic_region_bwd_args& b) { return b.sk > 1 ? b.sk : 1; }
+// The slice kernels split the streams over gridDim.z (workgroup z serves streams z, z+nz, ...):
+// with many streams and few regions the launch is bounded by the serial stream loop of a
+// workgroup, not by the weight rows it re-reads from L2.
 __device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int R, int r, int sk) {
-  for (int s = 0; s < S; ++s)
+  for (int s = blockIdx.z; s < S; s += gridDim.z)
     if (mask[(size_t)s * sk * R + r]) return true;
   return false;
 }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b, in
   }
   const bool rt = a.flags & IC_F_RT;
   const int SR = a.S * sk * a.R;
-  for (int s = 0; s < a.S; ++s) {
+  for (int s = blockIdx.z; s < a.S; s += gridDim.z) {
     const int row = s * sk * a.R + r;
     if (!a.mask[row]) continue;  // block-uniform
     const size_t off = (size_t)row * d;
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, in
   }
   const bool afd = a.flags & IC_F_AFD, vec = a.flags & IC_F_NOISE_VEC, rt = a.flags & IC_F_RT;
   const int SR = a.S * sk * a.R;
-  for (int s = 0; s < a.S; ++s) {
+  for (int s = blockIdx.z; s < a.S; s += gridDim.z) {
     const int row = s * sk * a.R + r;
     if (!a.mask[row]) continue;  // block-uniform
     const size_t off = (size_t)row * d;
@@ -644,7 +647,10 @@ extern "C" int ic_region_phase_bwd(const ic_region_bwd_args* b, ic_stream_t stre
   hipStream_t st = (hipStream_t)stream;
   const int rows = a->S * a->R;
   const int nslab = ic_bwd_nslab(a->d);
-  const dim3 blk(256), grow(ic_ceil_div(rows, 4)), gmat(nslab, a->R);
+  // stream split of the slice kernels: aim at >= 512 workgroups, at most one stream group per stream
+  int nz = 1;
+  while (nz < a->S && nz < 16 && nslab * a->R * nz < 512) nz *= 2;
+  const dim3 blk(256), grow(ic_ceil_div(rows, 4)), gmat(nslab, a->R, nz);
   const float oma = (float)(1.0 - a->pred_alpha);
   const bool soft = (a->flags & IC_F_KWTA_SOFT) && !(a->flags & IC_F_NOKWTA) && a->kwta_k > 0;
   const int fold = soft ? 0 : 1;

@@ -575,8 +575,8 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   const int src = is_q ? r : a.src[e];
   // block-uniform activity test
   const int sk = stream_step(b);
-  bool any = false;
-  for (int s = 0; s < a.S; ++s)
+  bool any = false;  // streams are split over gridDim.z as in the region backward
+  for (int s = blockIdx.z; s < a.S; s += gridDim.z)
     any |= is_q ? (b.tape_qact[(size_t)s * sk * a.R + r] != 0) : (prev_on(b, s, src));
   if (!any) return;
   const float* W = is_q ? a.query_W + (size_t)r * dd : a.W + (size_t)a.widx[e] * dd;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   }
   const float bias = is_q ? 1.0f : a.ebias[e];
   const int SE = a.S * sk * a.E, SR = a.S * sk * a.R;
-  for (int s = 0; s < a.S; ++s) {
+  for (int s = blockIdx.z; s < a.S; s += gridDim.z) {
     const int vs = s * sk;
     const bool act = is_q ? (b.tape_qact[(size_t)vs * a.R + r] != 0) : (prev_on(b, s, src));
     if (!act) continue;  // block-uniform
@@ -860,20 +860,22 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
   const int nslab = ic_bwd_nslab(a->d);
   const dim3 blk(256), grow(ic_ceil_div(a->S * a->R, 4));
   const int ny = a->E + ((a->flags & IC_RF_PRECISION) ? a->R : 0);
+  int nz = 1;
+  while (nz < a->S && nz < 16 && nslab * ny * nz < 512) nz *= 2;
   if (a->d <= 256) {
     constexpr int DCH = 1;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
-    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny), blk, 0, st, *b));
+    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else if (a->d <= 512) {
     constexpr int DCH = 2;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b));
-    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b));
+    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else {
     constexpr int DCH = 4;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b));
-    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny), blk, 0, st, *b));
+    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   }
   IC_LAUNCH_CHECK("ic_router_bwd");

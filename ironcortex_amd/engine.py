@@ -115,7 +115,7 @@ class _Sample:
     """Record of one loop: what the backward needs to replay the steps in reverse."""
 
     __slots__ = ("chunk", "i0", "n", "parent", "best", "step_pos", "init", "H0", "mask0", "sensor", "ebias",
-                 "norm_in_w", "flags", "kwta_k", "kwta_temp", "keep", "ebias_grad")
+                 "norm_in_w", "flags", "kwta_k", "kwta_temp", "keep", "ebias_grad", "zero_in")
 
 
 class LoopEngine:
@@ -132,6 +132,9 @@ class LoopEngine:
         self._sess = None  # C structs shared by the loops between two reset()s
         self._hs_ok = False
         self._fa_buf = None
+        self._batch = None  # loops of one reasoning_loop_batch call, differentiated as ONE node
+        self._wsb = None
+        self.counters = {"batch_bwd": 0, "loop_bwd": 0}  # backward passes taken all-loops-at-once / loop by loop
         model._coord.register(self._begin_pass, self._finish_pass)
 
     # ------------------------------------------------------------------ applicability
@@ -434,7 +437,12 @@ class LoopEngine:
             s.flags, s.kwta_k, s.kwta_temp = flags, kw_k, kw_temp
             s.keep = (focus_any, tables, rP, bP)
             s.ebias_grad = bool(ebias.requires_grad)
-            H_cur = LoopFn.apply(sensor, bank.anchor(dev), self, s)
+            s.zero_in = H_prev is getattr(m, "_zero_H", None)
+            if self._batch is not None:  # differentiated by end_batch() together with the other loops
+                self._batch["samples"].append(s)
+                H_cur = H_of(best)
+            else:
+                H_cur = LoopFn.apply(sensor, bank.anchor(dev), self, s)
         else:
             H_cur = H_of(best).clone()
         return H_cur, reg_mask, last_logits, traces
@@ -852,6 +860,232 @@ class LoopEngine:
         self._pass["blocks"].append((Z, n_r, s))
         return Z["gsens"].view(n_r * 2, d).sum(0)
 
+    # ------------------------------------------------------------------ loops of a batch as one node
+    def begin_batch(self, n_loops: int, n_max: int, dev) -> None:
+        """The next n_loops differentiable loops (reasoning_loop_batch) are recorded in ONE block of
+        step slots, preceded by a slot that holds the state the first loop starts from, and are
+        differentiated together by end_batch(): the reference detaches the region state between the
+        samples of a batch (model.py:482-487), so their backward passes are independent and the
+        same step of every loop can run as the streams of one launch."""
+        m = self.model
+        bank = m.bank
+        if bank.S != 1 or bank.num.device != dev:
+            bank.flat.reflat()
+            bank.reset_state(dev, 1)
+        need = n_loops * n_max + 1
+        arena = self._get_arena(dev, n_max)
+        if arena.chunk_steps < need:
+            self._rescue_state()
+            self._arena = arena = StepArena(self._shapes(), chunk_steps=need)
+        c, pos = arena.cur, arena.pos
+        if c < len(arena.chunks) and arena.chunks[c].cap - pos < need:
+            arena.cur, arena.pos = c + 1, 0  # the whole batch in one chunk
+        chunk, i = arena.reserve(1, dev)
+        f = chunk.fields
+        pairs = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o"), ("var", "var_o"), ("surprise", "surprise_o"),
+                 ("pred", "pred_o"), ("radius", "radius_o"), ("radius_var", "radius_var_o")]
+        for k, ko in pairs:  # the bank's state moves into the slot before the first loop
+            if ko in f:
+                f[ko][i].copy_(getattr(bank, k).reshape(f[ko][i].shape))
+                setattr(bank, k, f[ko][i:i + 1])
+        self._state_in_arena = True
+        self._batch = {"samples": [], "chunk": chunk, "base": i + 1, "n_max": n_max, "n_loops": n_loops}
+
+    def end_batch(self, sensors: torch.Tensor) -> Optional[torch.Tensor]:
+        """[n_recorded, R, d] final states of the recorded loops, as one autograd node whose input
+        is the batch of sensor vectors (row j of `sensors` fed recorded loop j)."""
+        bt, self._batch = self._batch, None
+        if bt is None or not bt["samples"]:
+            return None
+        return LoopBatchFn.apply(sensors, self.model.bank.anchor(sensors.device), self, bt)
+
+    def _batch_uniform(self, bt) -> bool:
+        """True when the recorded loops sit n_max slots apart in one chunk, ran all their steps from
+        the shared all-zero input state, and share parameters, flags and schedule."""
+        ss = bt["samples"]
+        s0, K = ss[0], bt["n_max"]
+        for j, s in enumerate(ss):
+            if s.chunk is not bt["chunk"] or s.i0 != bt["base"] + j * K or s.n != K or not s.zero_in:
+                return False
+            if (s.flags, s.kwta_k, s.kwta_temp) != (s0.flags, s0.kwta_k, s0.kwta_temp):
+                return False
+            if s.ebias.data_ptr() != s0.ebias.data_ptr() or s.norm_in_w is not s0.norm_in_w or s.keep[1] is not s0.keep[1]:
+                return False
+            if s.step_pos != s0.step_pos:
+                return False
+        return True
+
+    def _workspace_batch(self, device, V: int):
+        m = self.model
+        R, d, E = m.R, m.d, max(m.router.E, 1)
+        key = (device, V, R, d, E)
+        if self._wsb is not None and self._wsb["_key"] == key:
+            return self._wsb
+        ns = ops.bwd_nslab(d)
+        e = lambda *s: torch.empty(*s, device=device)
+        ws = {"gM": e(V, R, d), "ghpre": e(V, R, d), "slab2": e(ns, V, R, d), "slab": e(ns, V, R, d),
+              "slab_rt": e(ns, V, R), "gHd": e(V, R, d), "rslab": e(ns, V, E, d), "slab_q": e(ns, V, R, d)}
+        for side in ("a", "b"):
+            for k in ("gnum", "gden", "gvar", "gpred"):
+                ws[f"{k}_{side}"] = e(V, R, d)
+            for k in ("gradius", "gradius_var"):
+                ws[f"{k}_{side}"] = e(V, R)
+        ws["_ptr"] = {k: t.data_ptr() for k, t in ws.items()}
+        ws["_key"] = key
+        self._wsb = ws
+        return ws
+
+    def backward_batch(self, bt, gH_all: torch.Tensor) -> torch.Tensor:
+        """Backward of every recorded loop at once: step t of all S loops is one launch sequence
+        with S streams (spread sk = n_max slots apart in the arena, the tapes and the gradient
+        buffers), so a pass costs n_max launch sequences instead of S * n_max and every weight row
+        is read once per step for all loops.  Returns d/d sensors [S, d]."""
+        m = self.model
+        bank, router = m.bank, m.router
+        dev = gH_all.device
+        R, d, E = m.R, m.d, router.E
+        Ez = max(E, 1)
+        ss = bt["samples"]
+        S, K = len(ss), bt["n_max"]
+        V = S * K
+        s0 = ss[0]
+        L, st = lib(), stream_handle()
+        bank.coord.begin()
+        ws = self._workspace_batch(dev, V)
+        WP = ws["_ptr"]
+        ns = ops.bwd_nslab(d)
+        flags = s0.flags
+        afd, rt_, use_pred = bool(flags & ops.IC_F_AFD), bool(flags & ops.IC_F_RT), bool(flags & ops.IC_F_PRED)
+        prec = router.enable_precision_routed_messages
+        chunk, base = bt["chunk"], bt["base"]
+        CP, CS = chunk.ptr, chunk.stride
+
+        # ---- zero block: everything the kernels only write for active rows, [V, size] per field
+        zf = {"gH": R * d, "g_norm_w_rows": R * d, "g_raw_decay_rows": R * d, "g_norm_in_rows": R * d, "gsens": 2 * d,
+              "g_ebias_part": ns * Ez}
+        if afd:
+            zf.update(g_pn_rows=R * d, g_on_rows=R * d)
+        if rt_:
+            zf["g_rnoise_rows"] = R * 2
+        if prec:
+            zf["g_rawP_rows"] = Ez * d
+        pad = lambda n: (n + 63) // 64 * 64
+        zall = torch.zeros(sum(pad(V * sz) for sz in zf.values()), device=dev)
+        Z, zp, zoff = {}, {}, 0
+        for k, sz in zf.items():
+            Z[k] = zall[zoff:zoff + V * sz].view(V, sz)
+            zp[k] = Z[k].data_ptr()
+            zoff += pad(V * sz)
+        best = torch.tensor([s.best for s in ss], device=dev)
+        lanes = torch.arange(S, device=dev)
+        Z["gH"].view(S, K, R * d)[lanes, best] = gH_all.reshape(S, R * d)
+
+        # ---- tapes: one slot per (loop, step), laid out like the arena block
+        tape = bank.tape
+        t0 = tape.alloc_n(V, dev)
+        steps = torch.arange(K, device=dev)
+        live = steps[None, :] <= best[:, None]                      # [S,K]: steps that reach the loss
+        mk = chunk.fields["mask"][base:base + V].view(S, K, R) * live[:, :, None].to(_U8)
+        tape.buf["mask"][t0:t0 + V, 0].copy_(mk.view(V, R))          # the backward's own (masked) copy
+        tape.visited[t0:t0 + V].fill_(1)
+        mask_ptr, mask_stride = tape.buf["mask"].data_ptr() + t0 * tape.buf["mask"].stride(0), tape.buf["mask"].stride(0)
+        TB = {k: (tape.buf[k].data_ptr(), tape.buf[k].stride(0) * 4) for k in ("g", "x", "o")}
+        if E > 0:
+            rtape = router._get_tape(1, dev)
+            rt0 = rtape.alloc_n(V, dev)
+            RB = {k: (rtape.buf[k].data_ptr(), rtape.buf[k].stride(0) * rtape.buf[k].element_size())
+                  for k in rtape.buf}
+            # where each stream's step reads its input states: the parent's slot (relative to base)
+            par = torch.tensor([s.parent for s in ss], dtype=torch.int64, device=dev)       # [S,K]
+            slot = torch.where((par >= 0) & live, lanes[:, None] * K + par, torch.full_like(par, -1))
+            in_slot = slot.t().contiguous().to(torch.int32)                                   # [K,S]
+            rtape.visited[rt0:rt0 + V].copy_((slot >= 0).reshape(V).to(_U8))
+            r_live = [any(p >= 0 for p in col) for col in zip(*[s.parent for s in ss])]       # host: per step
+
+        # ---- structs
+        tables, rP, bP = s0.keep[1], s0.keep[2], s0.keep[3]
+        P = dict(bP)
+        P["norm_in_w"] = s0.norm_in_w
+        sens = torch.stack([s.sensor.reshape(-1) for s in ss]).contiguous()  # [S,d]
+        b = new("ic_region_bwd_args")
+        b.f = ops._region_args(bank.spec, P, S, 0.0, s0.kwta_k, flags, s0.kwta_temp)
+        b.f.sensor = sens.data_ptr()
+        b.sk = K
+        b.gM, b.ghpre, b.slab2, b.slab, b.slab_rt = WP["gM"], WP["ghpre"], WP["slab2"], WP["slab"], WP["slab_rt"]
+        saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
+            + (["sterm"] if afd else [])
+        state_in = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o")] + ([("var", "var_o")] if afd else []) \
+            + ([("pred", "pred_o")] if use_pred else []) \
+            + ([("radius", "radius_o"), ("radius_var", "radius_var_o")] if rt_ else [])
+        gnames = ["gnum", "gden"] + (["gvar"] if afd else []) + (["gpred"] if use_pred else []) \
+            + (["gradius", "gradius_var"] if rt_ else [])
+        rows = ["g_norm_w_rows", "g_raw_decay_rows", "g_norm_in_rows"] + (["g_pn_rows", "g_on_rows"] if afd else []) \
+            + (["g_rnoise_rows"] if rt_ else [])
+        bimg = StructImage(b)
+        bimg.linear(("f", "M"), CP["M"] + base * CS["M"], CS["M"])
+        bimg.linear(("f", "mask"), mask_ptr, mask_stride)
+        for k, ko in state_in:  # input state of step t = output of slot t - 1 (t == 0: the slot before the block)
+            bimg.linear(("f", k), CP[ko] + (base - 1) * CS[ko], CS[ko])
+        if rt_:
+            bimg.linear(("f", "radius_o"), CP["radius_o"] + base * CS["radius_o"], CS["radius_o"])
+        for k in saved:
+            bimg.linear(("f", k), CP[k] + base * CS[k], CS[k])
+        bimg.linear(("gH",), zp["gH"], R * d * 4)
+        bimg.linear(("gsens",), zp["gsens"], 2 * d * 4)
+        for k in rows:
+            bimg.linear((k,), zp[k], zf[k] * 4)
+        for k, fld in (("g", "tape_g"), ("x", "tape_x"), ("o", "tape_o")):
+            bimg.linear((fld,), TB[k][0] + t0 * TB[k][1], TB[k][1])
+        b_rows = bimg.images(range(K))
+        b_ref = ctypes.byref(b)
+        p_bwd, r_bwd = L.ic_region_phase_bwd, L.ic_router_bwd
+
+        if E > 0:
+            rb = new("ic_router_bwd_args")
+            rspec = ops.RouterSpec(R, d, E, router.nW, prec)
+            rb.f = ops._router_args(rspec, tables, rP, S)
+            rb.f.ebias = s0.ebias.data_ptr()
+            rb.f.M = WP["gM"]  # unused by the backward, must be non-NULL
+            rb.f.H, rb.f.mask_prev = CP["H"] + base * CS["H"], CP["mask"] + base * CS["mask"]
+            rb.src_off, rb.src_edges = tables["src_off"].data_ptr(), tables["src_edges"].data_ptr()
+            rb.slab, rb.gHd, rb.slab_q = WP["rslab"], WP["gHd"], WP["slab_q"]
+            rb.gM, rb.gH, rb.sk = WP["gM"], zp["gH"], K
+            rimg = StructImage(rb)
+            for k in (["msg", "keyv", "q", "wgt"] if prec else []):
+                rimg.linear(("f", k), CP[k] + base * CS[k], CS[k])
+            rimg.linear(("g_ebias_part",), zp["g_ebias_part"], Ez * 4)   # [ns, V, Ez] as the kernel sees it
+            if prec:
+                rimg.linear(("g_rawP_rows",), zp["g_rawP_rows"], Ez * d * 4)
+            for k, fld in (("gmsg", "tape_gmsg"), ("H", "tape_H"), ("eact", "tape_eact"), ("gkey", "tape_gkey"),
+                           ("gq", "tape_gq"), ("qact", "tape_qact")):
+                if k in RB:
+                    rimg.linear((fld,), RB[k][0] + rt0 * RB[k][1], RB[k][1])
+            rimg.linear(("in_slot",), in_slot.data_ptr(), S * 4)
+            r_rows = rimg.images(range(K))
+            rb_ref = ctypes.byref(rb)
+
+        side, have = "a", False
+        for t in range(K - 1, -1, -1):
+            bimg.load(b_rows[t])
+            b.f.step_pos = s0.step_pos[t]
+            other = "b" if side == "a" else "a"
+            for g in gnames:
+                setattr(b, g + "_o", WP[f"{g}_{side}"] if have else None)
+                setattr(b, g, WP[f"{g}_{other}"])
+            rc = p_bwd(b_ref, st)
+            if rc:
+                check(rc, "ic_region_phase_bwd")
+            side, have = other, True
+            if E > 0 and r_live[t]:
+                rimg.load(r_rows[t])
+                rc = r_bwd(rb_ref, st)
+                if rc:
+                    check(rc, "ic_router_bwd")
+
+        self._pass["blocks"].append((Z, V, s0))
+        self._pass.setdefault("keep", []).append((sens, best, in_slot if E > 0 else None, mk))
+        return Z["gsens"].view(S, K * 2, d).sum(1)
+
     # ------------------------------------------------------------------ per-pass reductions
     def _begin_pass(self) -> None:
         self._pass = {"blocks": []}
@@ -917,3 +1151,27 @@ class LoopFn(torch.autograd.Function):
     def backward(ctx, gH):
         g_sensor = ctx.engine.backward(ctx.sample, gH.contiguous())
         return g_sensor.view(ctx.sshape), None, None, None
+
+
+class LoopBatchFn(torch.autograd.Function):
+    """One autograd node for all the loops of a reasoning_loop_batch call (LoopEngine.begin_batch /
+    end_batch): forward stacks the loops' final region states, backward replays every loop's steps
+    in reverse -- all loops at once when they are laid out uniformly, else one after another."""
+
+    @staticmethod
+    def forward(ctx, sensors, anchor, engine, bt):
+        ctx.engine, ctx.bt = engine, bt
+        ctx.sshape = sensors.shape
+        return torch.stack([s.chunk.fields["H"][s.i0 + s.best] for s in bt["samples"]])
+
+    @staticmethod
+    def backward(ctx, gH):
+        eng, bt = ctx.engine, ctx.bt
+        gH = gH.contiguous()
+        if eng._batch_uniform(bt):
+            eng.counters["batch_bwd"] += 1
+            g = eng.backward_batch(bt, gH)
+        else:
+            eng.counters["loop_bwd"] += len(bt["samples"])
+            g = torch.stack([eng.backward(s, gH[j]) for j, s in enumerate(bt["samples"])])
+        return g.view(ctx.sshape), None, None, None

@@ -381,8 +381,17 @@ class CortexReasoner(nn.Module):
         batched = None
         if N > 1 and tokens_batch.is_cuda and not self.cfg.ff_dropout and not self.cfg.profile:
             batched = self.sensor_vectors_batch(tokens_batch, focus_batch)  # the loops only differ in region state
+        eng = self.engine
         try:
             H_zero, mask_zero = self.zeros_state(dev)  # never written to: shared by all loops
+            self._zero_H = H_zero
+            # train_step: the loops are independent in the backward (state detached between samples),
+            # so the engine records them in one block and differentiates them as ONE node
+            one_node = (batched is not None and torch.is_grad_enabled() and self._logits_detached
+                        and eng.usable(H_zero, False))
+            if one_node:
+                eng.begin_batch(N, K_inner * (1 if self.cfg.train_deterministic_inner_loop else max(1, self.cfg.B_br)), dev)
+            recorded = []
             for b in range(N):
                 self.detach_state()
                 H_prev, mask_prev = H_zero, mask_zero
@@ -391,11 +400,24 @@ class CortexReasoner(nn.Module):
                     self.local_mix.last_energy = batched[1][b]
                     if batched[2] is not None:
                         self.local_mix.attn.last_attn_entropy = batched[2][b]
+                n_rec = len(eng._batch["samples"]) if one_node else 0
                 H_cur, reg_mask, logits, traces = self.reasoning_loop(tokens_batch[b], K_inner, focus_batch[b], mask_prev, H_prev)
+                if one_node and len(eng._batch["samples"]) > n_rec:
+                    recorded.append(b)  # H_cur is a placeholder until end_batch()
                 H_l.append(H_cur); M_l.append(reg_mask); L_l.append(logits); T_l.append(traces)
                 E_l.append(self.local_mix.last_energy.detach())
                 ent = getattr(getattr(self.local_mix, "attn", None), "last_attn_entropy", torch.tensor(0.0))
                 A_l.append(ent.detach().to(dev))
+            if one_node:
+                H_eng = eng.end_batch(batched[0][recorded] if len(recorded) != N else batched[0])
+                if len(recorded) == N:
+                    H_l = H_eng  # [N,R,d]
+                else:
+                    for j, b in enumerate(recorded):
+                        H_l[b] = H_eng[j]
         finally:
             self._sensor_override = None
-        return (torch.stack(H_l), torch.stack(M_l), torch.stack(L_l), T_l, torch.stack(E_l), torch.stack(A_l))
+            self._zero_H = None
+            eng._batch = None
+        H_all = H_l if torch.is_tensor(H_l) else torch.stack(H_l)
+        return (H_all, torch.stack(M_l), torch.stack(L_l), T_l, torch.stack(E_l), torch.stack(A_l))
