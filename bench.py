@@ -54,19 +54,17 @@ WORKLOAD = {"10m": "train_tiny_shakespeare_10m.py config (R=10,d=256,all flags o
 
 
 def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
-    """fp32 bytes one launch must move, from per-launch averages:
-    n = active (stream,region) pairs, e = active edges, q = regions with an active in-edge."""
-    n, e, q, R, afd, prec = st["n"], st["e"], st["q"], st["R"], st["afd"], st["prec"]
+    """fp32 bytes one launch must move (u*16d^2-class weight bytes + n*vectors),
+    from per-launch averages counted on the device: n = (stream, region) pairs served, u = distinct
+    regions among them (a launch reads a region's weights once for all its streams)."""
+    afd = st["afd"]
     dd = 4.0 * d * d
     vec = 4.0 * d
     table = {
-        "region_rkv": n * (3 * dd + (10 + (5 if afd else 0)) * vec),
-        "region_out": n * (dd + 3 * vec),
-        "region_rkv_bwd": n * (3 * dd + (16 + (6 if afd else 0)) * vec),
-        "region_out_bwd": n * (dd + 4 * vec),
-        "router_fwd": e * (dd + vec) + R * vec,
-        "router_edge_fwd": e * (2 * dd + 3 * vec) + q * (dd + 2 * vec),
-        "router_mat_bwd": e * ((2 if prec else 1) * dd + 4 * vec) + (q * (dd + 2 * vec) if prec else 0),
+        "region_rkv": st["u_f"] * 3 * dd + st["n_f"] * (10 + (5 if afd else 0)) * vec,
+        "region_out": st["u_f"] * dd + st["n_f"] * 3 * vec,
+        "region_rkv_bwd": st["u_b"] * 3 * dd + st["n_b"] * (16 + (6 if afd else 0)) * vec,
+        "region_out_bwd": st["u_b"] * dd + st["n_b"] * 4 * vec,
     }
     return table.get(kernel, 0.0)
 
@@ -177,7 +175,8 @@ def main():
     model.count_units(True)
     dominant = None
     if timing:
-        cand = [k for k in survey if algorithmic_bytes(k, cfg.d, dict(n=1, e=1, q=1, R=R, afd=0, prec=0)) > 0]
+        unit = dict(u_f=1, n_f=1, u_b=1, n_b=1, afd=0)
+        cand = [k for k in survey if algorithmic_bytes(k, cfg.d, unit) > 0]
         if cand:
             dominant = max(cand, key=lambda k: survey[k][1])
         # timed region: only the dominant kernel carries events (two event records per launch would
@@ -217,12 +216,13 @@ def main():
         roof = None
         if prof:
             lib_ms = sum(ms for _, ms in survey.values()) if survey else sum(ms for _, ms in prof.values())
-            name = dominant or max((k for k in prof if algorithmic_bytes(k, cfg.d, dict(n=1, e=1, q=1, R=R, afd=0, prec=0)) > 0),
+            name = dominant or max((k for k in prof if algorithmic_bytes(k, cfg.d, dict(u_f=1, n_f=1, u_b=1, n_b=1, afd=0)) > 0),
                                    key=lambda k: prof[k][1])
             launches, ms = prof[name]
-            inner = max(1, units["inner_steps"])
-            st = dict(n=units["region_steps"] / inner, e=units["active_edges"] / inner, q=units["dst_regions"] / inner,
-                      R=R, afd=cfg.enable_adaptive_filter_dynamics, prec=cfg.enable_precision_routed_messages)
+            lf, lb = max(1.0, units["fwd_region_launches"]), max(1.0, units["bwd_region_launches"])
+            st = dict(n_f=units["region_steps"] / lf, u_f=units["fwd_unique_regions"] / lf,
+                      n_b=units["bwd_pairs"] / lb, u_b=units["bwd_unique_regions"] / lb,
+                      afd=cfg.enable_adaptive_filter_dynamics)
             ab = algorithmic_bytes(name, cfg.d, st)
             avg_s = ms / launches * 1e-3
             achieved = ab / avg_s / 1e9
@@ -230,7 +230,8 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, args.config), "launches": launches,
                     "launch_sampling": f"HIP events on 1 launch in {PROF_STRIDE} over the timed region",
                     "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ab,
-                    "units_per_launch": {"active_regions": st["n"], "active_edges": st["e"]},
+                    "units_per_launch": ({"pairs": st["n_b"], "distinct_regions": st["u_b"]} if name.endswith("_bwd")
+                                         else {"pairs": st["n_f"], "distinct_regions": st["u_f"]}),
                     "library_kernel_ms_per_step": lib_ms / (1 if survey else args.steps),
                     "note": "working set fits the 256 MB Infinity Cache; launches are latency-bound at this size "
                             "(see profiles/ for the R=64..512 kernel sweep)"}

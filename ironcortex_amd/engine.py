@@ -471,7 +471,11 @@ class LoopEngine:
             masks = allm[torch.tensor(steps, device=dev)]
             ea = allm[torch.tensor(prevs, device=dev)][:, m.router.src_idx]  # [n,E]
             into = torch.zeros(len(steps), m.R, device=dev).index_add_(1, m.router.dst_idx, ea)
-            m._units += torch.stack([masks.sum(), ea.sum(), (into > 0).sum().float()])
+            # region-phase launches: the nb branches of an outer iteration are the streams of one launch
+            nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
+            grp = masks.view(-1, nb, m.R) if len(steps) % nb == 0 else masks.view(-1, 1, m.R)
+            m._units[:5] += torch.stack([masks.sum(), ea.sum(), (into > 0).sum().float(),
+                                         torch.tensor(float(grp.shape[0]), device=dev), grp.amax(1).sum()])
 
     # ------------------------------------------------------------------ loop heads (HIP, no autograd)
     def _heads_setup(self, dev):
@@ -857,6 +861,9 @@ class LoopEngine:
 
         # ---- the small parameter gradients are reduced ONCE per backward pass (_finish_pass): the
         # per-step rows of this loop are only queued here
+        if m._units is not None:
+            n_on = chunk.fields["mask"][i0:i0 + n_r].sum().float()
+            m._units[5:8] += torch.stack([torch.tensor(float(n_r), device=dev), n_on, n_on])
         self._pass["blocks"].append((Z, n_r, s))
         return Z["gsens"].view(n_r * 2, d).sum(0)
 
@@ -1082,6 +1089,8 @@ class LoopEngine:
                 if rc:
                     check(rc, "ic_router_bwd")
 
+        if m._units is not None:
+            m._units[5:8] += torch.stack([torch.tensor(float(K), device=dev), mk.sum().float(), mk.amax(0).sum().float()])
         self._pass["blocks"].append((Z, V, s0))
         self._pass.setdefault("keep", []).append((sens, best, in_slot if E > 0 else None, mk))
         return Z["gsens"].view(S, K * 2, d).sum(1)

@@ -110,14 +110,17 @@ class CortexReasoner(nn.Module):
     def count_units(self, on: bool) -> None:
         """Count region steps / active edges on the device (no sync) for throughput reports."""
         dev = self.reg_coords.device
-        self._units = torch.zeros(3, device=dev) if on else None
+        self._units = torch.zeros(8, device=dev) if on else None
         self.counters["inner_steps"] = 0
 
     def read_units(self) -> Dict[str, float]:
         self.engine.flush_units()
-        u = self._units.tolist() if self._units is not None else [0.0, 0.0, 0.0]
+        u = self._units.tolist() if self._units is not None else [0.0] * 8
+        # region-phase launches and, per launch, the (stream, region) pairs served and the distinct
+        # regions among them (their weights are read once per launch): forward / backward
         return {"inner_steps": self.counters["inner_steps"], "region_steps": u[0], "active_edges": u[1],
-                "dst_regions": u[2]}
+                "dst_regions": u[2], "fwd_region_launches": u[3], "fwd_unique_regions": u[4],
+                "bwd_region_launches": u[5], "bwd_pairs": u[6], "bwd_unique_regions": u[7]}
 
     def detach_state(self) -> None:
         if hasattr(self, "work"):
@@ -234,7 +237,8 @@ class CortexReasoner(nn.Module):
         if self._units is not None and self.router.E > 0:
             ea = reg_mask_prev.to(torch.float32)[self.router.src_idx]
             into = torch.zeros(self.R, device=dev).index_add_(0, self.router.dst_idx, ea)
-            self._units += torch.stack([mask.sum().float(), ea.sum(), (into > 0).sum().float()])
+            n_act = mask.sum().float()
+            self._units[:5] += torch.stack([n_act, ea.sum(), (into > 0).sum().float(), torch.ones_like(n_act), n_act])
         # 4) heads on motor & workspace -- no host sync: the active set stays on the device
         logits, rtd_logits, ws_state, motor_state = self._heads(H_cur, mask[0])
         return H_cur, mask[0].bool(), logits, rtd_logits, ws_state, motor_state
