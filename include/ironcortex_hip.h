@@ -335,6 +335,10 @@ typedef struct ic_gemv_desc {
 } ic_gemv_desc;
 /* descs is a HOST array; the n GEMVs run in order on the stream (each may read the previous y). */
 int ic_gemv_chain(const ic_gemv_desc* descs, int32_t n, ic_stream_t stream);
+/* n <= 4 INDEPENDENT GEMVs as one launch (e.g. layer i of the verifier and layer i of the planner
+ * chain, which do not read each other).  With score != NULL, descs[0] is the verifier's last
+ * layer and gets the branch-score epilogue of ic_verify_score. */
+int ic_gemv_multi(const ic_gemv_desc* descs, int32_t n, const float* stats, float* score, ic_stream_t stream);
 
 /* Workspace write + token logits of one inner step (model.py:296-318, heads.py:26-29,96-119):
  *   slots_out = KWTA(slots_in + delta, d/4), delta[j] = H of the j-th active region (index order);
@@ -369,6 +373,8 @@ typedef struct ic_heads_args {
   int32_t S;                /* 0 or 1 = one step */
   int64_t Hpar_sstride;     /* elements between consecutive streams' H_par blocks */
   int64_t slots_in_sstride; /* elements between consecutive streams' slots_in blocks */
+  float* ws_mean;           /* [S,d] or NULL: mean of the active rows of H (zeros when none) -- the planner's
+                               input for the NEXT outer iteration should this step win (model.py:344-349) */
 } ic_heads_args;
 int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
 

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_gemv(ic_gemv_desc g0, const float* stat
 // (lane-strided, L2 hits) TOGETHER with its two weight rows, and computes the LayerNorm
 // statistics itself -- no LDS staging, no workgroup barrier, one memory round trip.
 template <int NX>
-__global__ __launch_bounds__(256) void k_gemv_reg(ic_gemv_desc g0, const float* stats, float* score) {
+__device__ __forceinline__ void gemv_reg_body(const ic_gemv_desc& g0, const float* stats, float* score) {
   const ic_gemv_desc g = gemv_batch(g0, blockIdx.y);
   if (score) {
     stats += 4 * blockIdx.y;
@@ -154,6 +154,22 @@ __global__ __launch_bounds__(256) void k_gemv_reg(ic_gemv_desc g0, const float* 
     // the verifier's last layer: energy -> branch score (model.py:431-438)
     if (score && row0 == 0) score[0] = 0.6f * stats[2] + 0.2f * (-o0) + 0.2f * stats[1];
   }
+}
+
+template <int NX>
+__global__ __launch_bounds__(256) void k_gemv_reg(ic_gemv_desc g0, const float* stats, float* score) {
+  gemv_reg_body<NX>(g0, stats, score);
+}
+
+// Up to 4 independent GEMVs in one launch: blockIdx.z selects the descriptor.
+struct MultiArgs {
+  ic_gemv_desc d[4];
+};
+template <int NX>
+__global__ __launch_bounds__(256) void k_gemv_multi(MultiArgs m, const float* stats, float* score) {
+  const ic_gemv_desc& g0 = m.d[blockIdx.z];
+  if ((int)blockIdx.x * 8 >= g0.rows || (int)blockIdx.y >= (g0.nbatch > 1 ? g0.nbatch : 1)) return;
+  gemv_reg_body<NX>(g0, blockIdx.z == 0 ? stats : nullptr, blockIdx.z == 0 ? score : nullptr);
 }
 
 // A whole chain of small GEMVs in ONE workgroup (16 waves): layer i+1 reads layer i's output
@@ -552,7 +568,22 @@ __device__ __forceinline__ ic_heads_args heads_stream(ic_heads_args a, int s) {
   a.probs += (size_t)s * a.V;
   a.stats += 4 * s;
   if (a.aux_surprise) a.aux_surprise += 4 * s;
+  if (a.ws_mean) a.ws_mean += (size_t)s * a.d;
   return a;
+}
+
+// mean of the active rows of H (same arithmetic as k_steer_select): one workgroup per stream
+__device__ __forceinline__ void ws_mean_rows(const ic_heads_args& a) {
+  if (blockIdx.x != 0) return;
+  float n_on = 0.f;
+  for (int r = 0; r < a.R; ++r) n_on += a.mask[r] ? 1.0f : 0.0f;
+  const float den = fmaxf(n_on, 1.0f);
+  for (int c = threadIdx.x; c < a.d; c += 256) {
+    float s = 0.f;
+    for (int r = 0; r < a.R; ++r)
+      if (a.mask[r]) s += a.H[(size_t)r * a.d + c];
+    a.ws_mean[c] = s / den;
+  }
 }
 
 template <int DCH>
@@ -561,6 +592,7 @@ __global__ __launch_bounds__(256) void k_heads(ic_heads_args a0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.y == a.R + 1) ws_write_rows<DCH>(a, lane, wave);
   else if ((int)blockIdx.y == a.R + 2) sq_rows<DCH>(a, lane, wave);
+  else if ((int)blockIdx.y == a.R + 3) ws_mean_rows(a);
   else token_rows<DCH>(a, lane, wave);
 }
 
@@ -684,6 +716,31 @@ extern "C" int ic_gemv_chain(const ic_gemv_desc* descs, int32_t n, ic_stream_t s
   return IC_OK;
 }
 
+extern "C" int ic_gemv_multi(const ic_gemv_desc* descs, int32_t n, const float* stats, float* score,
+                             ic_stream_t stream) {
+  IC_REQUIRE(descs != nullptr && n >= 1 && n <= 4, "ic_gemv_multi: n=%d (need 1..4 descriptors)", n);
+  IC_REQUIRE(!score || (stats && descs[0].rows == 1), "ic_gemv_multi: score needs stats and a scalar descs[0]");
+  MultiArgs m;
+  int rows = 0, cols = 0, nb = 1;
+  for (int i = 0; i < n; ++i) {
+    int rc = check_gemv(descs[i], i, "ic_gemv_multi");
+    if (rc) return rc;
+    m.d[i] = descs[i];
+    rows = descs[i].rows > rows ? descs[i].rows : rows;
+    const int c = descs[i].n0 + descs[i].n1 + descs[i].n2;
+    cols = c > cols ? c : cols;
+    nb = descs[i].nbatch > nb ? descs[i].nbatch : nb;
+  }
+  IC_REQUIRE(cols <= 1024, "ic_gemv_multi: %d input columns (need <= 1024)", cols);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(ic_ceil_div(rows, 8), nb, n), blk(256);
+  if (cols <= 256) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_multi<4>, grid, blk, 0, st, m, stats, score));
+  else if (cols <= 512) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_multi<8>, grid, blk, 0, st, m, stats, score));
+  else IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_multi<16>, grid, blk, 0, st, m, stats, score));
+  IC_LAUNCH_CHECK("ic_gemv_multi");
+  return IC_OK;
+}
+
 extern "C" int ic_verify_score(const ic_gemv_desc* descs, int32_t n, const float* stats, float* score,
                                ic_stream_t stream) {
   IC_REQUIRE(descs != nullptr && n >= 1 && stats && score, "ic_verify_score: NULL argument");
@@ -713,7 +770,7 @@ extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
   int nx = ic_ceil_div(max_rows, 8);
   if (ic_ceil_div(a->n_slots, 4) > nx) nx = ic_ceil_div(a->n_slots, 4);
   IC_DISPATCH_DCH(a->d, {
-    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 3 + a->R, S), dim3(256), 0, st, *a));
+    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 3 + a->R + (a->ws_mean ? 1 : 0), S), dim3(256), 0, st, *a));
   });
   IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(S), dim3(256), 0, st, *a));
   IC_LAUNCH_CHECK("ic_heads_fwd");

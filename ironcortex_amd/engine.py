@@ -501,7 +501,10 @@ class LoopEngine:
         R, d, V, Kf = m.R, m.d, m.V, m.lm_head.Kf
         z = lambda *s: torch.zeros(*s, device=dev)
         # per-branch scratch blocks are contiguous: branch b of a batched call uses block b
-        buf = dict(ls=z(64), ws_prev=z(d), motor=z(d), p_h=z(d), p=z(d), g_h=z(2 * d), g=z(d), c_h=z(2 * d),
+        # planner / critic scratch: one block per candidate branch (the chain runs for both branches
+        # of an outer iteration before their scores say which one steers the next iteration)
+        buf = dict(ls=z(64), ws_prev=z(nb, d), motor=z(d), p_h=z(nb, d), p=z(nb, d), g_h=z(nb, 2 * d), g=z(nb, d),
+                   c_h=z(nb, 2 * d),
                    z=z(nb, Kf + Kf * V), per_region=z(nb, R, V), probs=z(nb, V), aux=z(nb, 4), gsq=z(nb, 2 * R))
         P = {k: t.data_ptr() for k, t in buf.items()}
         G = CLASSES["ic_gemv_desc"]
@@ -544,9 +547,18 @@ class LoopEngine:
             desc(steer[2], mods[3], [(P["p"], d), (P["ws_prev"], d)], P["g_h"], gelu)
             desc(steer[3], mods[4], [(P["g_h"], 2 * d)], P["g"], none)
             desc(steer[4], mods[5], [(P["ws_prev"], d), (P["g"], d)], P["c_h"], gelu)  # heads.py:69-70
-            desc(steer[5], mods[6], [(P["c_h"], 2 * d)], P["ls"] + 40 * 4, none)
+            desc(steer[5], mods[6], [(P["c_h"], 2 * d)], P["ls"] + 40 * 4, none)  # v_hat of candidate b at ls[40 + b]
+            for g_, (xb, yb) in zip(steer, (((d,), d), ((d,), d), ((d, d), 2 * d), ((2 * d,), d), ((d, d), 2 * d),
+                                             ((2 * d,), 1))):
+                g_.x0_bs, g_.y_bs = xb[0], yb
+                if len(xb) > 1:
+                    g_.x1_bs = xb[1]
         sa = new("ic_steer_args", R=R, d=d, motor_idx=m.io_idxs["motor"], ws_prev=buf["ws_prev"], motor=buf["motor"])
-        self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods, nb=nb)
+        # layer i of the verifier next to layer i of the planner chain, for ic_gemv_multi (refreshed per call)
+        pairs = [(G * 2)() for _ in range(3)] if (ver is not None and steer is not None) else None
+        tail = (G * 3)() if steer is not None else None
+        self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods, nb=nb, pairs=pairs,
+                        tail=tail)
         return self._hs
 
     def _drive(self, steps, in_ptrs, H_of, K_inner, dev, chunk, i0, trace_views=False):
@@ -605,15 +617,36 @@ class LoopEngine:
                 check(rc, "ic_heads_fwd")
             return True
 
-        def verify(first: int, n: int) -> None:
-            """Verifier energy + branch score of n consecutive steps (batched layers)."""
+        pairs_, tail_ = hs["pairs"], hs["tail"]
+        multi = L.ic_gemv_multi
+
+        def verify(first: int, n: int, plan_too: bool) -> None:
+            """Verifier energy + branch score of n consecutive steps (batched layers).  plan_too: the
+            planner -> critic chain of the NEXT outer iteration runs for all n candidates in the same
+            launches (its input, the mean of each step's active rows, was written by the heads): the
+            first three layers ride with the verifier's, the rest follow; the host picks the winner's
+            v_hat once the scores are read."""
             ver[0].x0 = CP["H"] + (i0 + first) * CS["H"] + motor * d * 4
             ver[2].y = lsp + 48 * 4
             for g in ver:
                 g.nbatch = n
-            rc = vscore(ver, 3, lsp + 8 * 4, lsp, st)
+            if not plan_too:
+                rc = vscore(ver, 3, lsp + 8 * 4, lsp, st)
+                if rc:
+                    check(rc, "ic_verify_score")
+                return
+            for g in steer:
+                g.nbatch = n
+            for i_ in range(3):
+                pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_]
+                rc = multi(pairs_[i_], 2, lsp + 8 * 4, lsp if i_ == 2 else None, st)
+                if rc:
+                    check(rc, "ic_gemv_multi")
+            for i_ in range(3):
+                tail_[i_] = steer[3 + i_]
+            rc = chain(tail_, 3, st)
             if rc:
-                check(rc, "ic_verify_score")
+                check(rc, "ic_gemv_chain")
 
         last = -1
         traces: List[torch.Tensor] = []
@@ -635,31 +668,40 @@ class LoopEngine:
         B_br = cfg.B_br
         branches = [(-1, -1) for _ in range(B_br)]  # (step whose workspace slots, step whose H / mask)
         u_mean = 0.0
+        planned = False  # True when the previous iteration already ran the planner for both candidates
         for k in range(K_inner):
-            # planner / critic on the best candidate so far, chosen on the device (model.py:371-386)
-            sa.n_cand = len(branches)
-            for c, (_, hstep) in enumerate(branches):
-                sa.H_cand[c], sa.mask_cand[c] = in_ptrs(hstep, c)
-            sa.scores = lsp if k > 0 else None
-            rc = steer_sel(sa_ref, st) or chain(steer, 6, st)
-            if rc:
-                check(rc, "ic_steer_select/ic_gemv_chain")
+            if not planned:
+                # planner / critic on the best candidate so far, chosen on the device (model.py:371-386)
+                sa.n_cand = len(branches)
+                for c, (_, hstep) in enumerate(branches):
+                    sa.H_cand[c], sa.mask_cand[c] = in_ptrs(hstep, c)
+                sa.scores = lsp if k > 0 else None
+                for g in steer:
+                    g.nbatch = 1
+                rc = steer_sel(sa_ref, st) or chain(steer, 6, st)
+                if rc:
+                    check(rc, "ic_steer_select/ic_gemv_chain")
             vals = ls.tolist()  # the one host sync of this outer iteration
+            v_hat = vals[40]
             if k > 0:
                 top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
+                if planned:
+                    v_hat = vals[40 + top[0]]  # the winner's, from the chain run for every candidate
                 branches = [branches[i] for i in top]
                 traces.append(keep(H_of(branches[0][1])))
                 u_mean = vals[8 + 4 * (B_br - 1)]
-            v_hat = vals[40]
             gate.value_bias = v_hat
             burst = schedule_burst(u_mean, v_hat, m.R)
             pars = [branches[b][1] for b in range(B_br)]   # IndexError for B_br > 2, as in the reference
             sls = [branches[b][0] for b in range(B_br)]
             ids = front(pars, k, u_mean, burst, st)          # gate + router of every branch
             region(ids[0], st, len(ids))                     # the branches share the state chain
+            # will there be a next iteration?  (should_halt only looks at this iteration's u_mean)
+            planned = k + 1 < K_inner and not should_halt(None, u_mean, k, K_inner) and len(ids) <= 8
+            ha.ws_mean = P["ws_prev"] if planned else None
             if not heads(ids, pars, sls):
                 raise RuntimeError("LoopEngine: branch inputs are not equally spaced (B_br > 2 is not supported)")
-            verify(ids[0], len(ids))
+            verify(ids[0], len(ids), planned)
             branches = [(cur, cur) for cur in ids]
             last = ids[-1]
             if should_halt(None, u_mean, k, K_inner):

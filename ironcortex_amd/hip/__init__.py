@@ -103,6 +103,8 @@ def lib():
         vp = ctypes.c_void_p  # raw device addresses are passed as Python ints: declare them 64-bit
         _lib.ic_branch_score.argtypes = [vp, vp, vp, vp]
         _lib.ic_gemv_chain.argtypes = [vp, ctypes.c_int32, vp]
+        _lib.ic_gemv_multi.argtypes = [vp, ctypes.c_int32, vp, vp, vp]
+        _lib.ic_front_fwd.argtypes = [vp, vp, vp]
         _lib.ic_verify_score.argtypes = [vp, ctypes.c_int32, vp, vp, vp]
     return _lib
 

@@ -122,8 +122,8 @@ def test_steer_chain_and_verify_score_vs_oracle():
     sa.scores = sc.data_ptr()
     hip.check(L.ic_steer_select(ctypes.byref(sa), st) or L.ic_gemv_chain(hs["steer"], 6, st), "steer")
     torch.cuda.synchronize()
-    close(buf["ws_prev"], ws_prev, what="ws_prev")
-    close(buf["g"], g, what="subgoal g")
+    close(buf["ws_prev"][0], ws_prev, what="ws_prev")
+    close(buf["g"][0], g, what="subgoal g")
     close(buf["ls"][40], v_hat, what="v_hat")
     # no scores -> candidate 0; no active region -> zeros (model.py:374-375)
     sa.scores = None
@@ -131,7 +131,7 @@ def test_steer_chain_and_verify_score_vs_oracle():
     sa.mask_cand[0] = zero_mask.data_ptr()
     hip.check(L.ic_steer_select(ctypes.byref(sa), st), "steer")
     torch.cuda.synchronize()
-    assert float(buf["ws_prev"].abs().max()) == 0.0
+    assert float(buf["ws_prev"][0].abs().max()) == 0.0
     close(buf["motor"], cands[0][0][motor], what="motor row")
     # ---- verifier energy + branch score (energy.py:12-30, model.py:425-438)
     g2 = torch.Generator().manual_seed(9)
@@ -313,3 +313,49 @@ def test_cooperative_chain_equals_layer_by_layer():
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), ("cooperative chain differs from layer-by-layer", k)
     assert float(outs[1]["ls"][40]) != 0.0 and float(outs[1]["ls"][0]) != 0.0
+
+
+def test_planner_for_both_candidates_in_the_verifier_launches():
+    """The engine's merged launches (ic_gemv_multi: verifier layer i next to planner layer i, both
+    batched over the two branches) == the two chains run separately, bit for bit."""
+    from ironcortex_amd import hip
+    cfg, prod, _ = build_pair("allflags")
+    R, d, V = cfg.R, cfg.d, cfg.V
+    dev = torch.device(DEV)
+    L, st = hip.lib(), hip.stream_handle()
+    hs_ = prod.engine._heads_setup(dev)
+    steer, ver, buf, pairs, tail = hs_["steer"], hs_["ver"], hs_["buf"], hs_["pairs"], hs_["tail"]
+    g = torch.Generator().manual_seed(21)
+    Hc = (torch.randn(2, R, d, generator=g) * (torch.rand(2, R, d, generator=g) < 0.3)).to(DEV)
+    ws = torch.randn(2, d, generator=g).to(DEV)
+    pr = torch.softmax(torch.randn(2, V, generator=g), -1).to(DEV)
+    stats = torch.tensor([0.0, -1.5, 0.25, 0.0, 0.0, -2.0, 0.5, 0.0], device=DEV)
+    outs = []
+    for merged in (False, True):
+        for k in ("p_h", "p", "g_h", "g", "c_h", "h1", "h2", "ls"):
+            buf[k].zero_()
+        buf["ws_prev"].copy_(ws)
+        buf["probs"].copy_(pr)
+        ls = buf["ls"]
+        ls[8:16].copy_(stats)
+        ver[0].x0 = Hc.data_ptr() + (R - 1) * d * 4
+        ver[2].y = ls.data_ptr() + 48 * 4
+        for g_ in list(ver) + list(steer):
+            g_.nbatch = 2
+        if merged:
+            for i in range(3):
+                pairs[i][0], pairs[i][1] = ver[i], steer[i]
+                hip.check(L.ic_gemv_multi(pairs[i], 2, ls.data_ptr() + 32, ls.data_ptr() if i == 2 else None, st), "multi")
+            for i in range(3):
+                tail[i] = steer[3 + i]
+            hip.check(L.ic_gemv_chain(tail, 3, st), "tail")
+        else:
+            hip.check(L.ic_verify_score(ver, 3, ls.data_ptr() + 32, ls.data_ptr(), st), "verify")
+            hip.check(L.ic_gemv_chain(steer, 6, st), "chain")
+        torch.cuda.synchronize()
+        outs.append({k: buf[k].clone() for k in ("p_h", "p", "g_h", "g", "c_h", "h1", "h2", "ls")})
+    for g_ in list(ver) + list(steer):
+        g_.nbatch = 0
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert float(outs[1]["ls"][40]) != float(outs[1]["ls"][41]) and float(outs[1]["ls"][0]) != 0.0
