@@ -28,6 +28,19 @@ opt.step = timed("opt.step", opt.step)
 orig_bwd = torch.Tensor.backward
 torch.Tensor.backward = timed("total.backward", orig_bwd)
 m.finalize_grads = timed("finalize_grads", m.finalize_grads)
+m.sensor_vectors_batch = timed("sensor_vectors_batch(mixer, batched)", m.sensor_vectors_batch)
+m.reasoning_loop_batch = timed("reasoning_loop_batch(total)", m.reasoning_loop_batch)
+opt.zero_grad = timed("opt.zero_grad", opt.zero_grad)
+m.detach_state = timed("detach_state", m.detach_state)
+m.train = timed("model.train()", m.train)
+from ironcortex_amd.hip import ops as _ops
+_ops.hebbian_rank1 = timed("hebbian_rank1", _ops.hebbian_rank1)
+T.ops.hebbian_rank1 = _ops.hebbian_rank1
+m.lm_head.forward_rows = timed("lm_head.forward_rows", m.lm_head.forward_rows)
+m.verify.forward = timed("verify.forward(x2)", m.verify.forward)
+m.gate.update_homeo = timed("update_homeo", m.gate.update_homeo)
+_fn = torch._foreach_norm
+torch._foreach_norm = timed("foreach_norm", _fn)
 for i in range(3):
     ic.train_step(m, opt, toks, ic.LossWeights(), dev)
 acc.clear()
