@@ -112,3 +112,31 @@ def test_generation_smoke():
     assert out2.shape == (12,) and torch.equal(out2[:3], prompt)
     t = model.telemetry()
     assert "regions" in t and len(t["regions"]) == cfg.R
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_batched_backward_equals_loop_by_loop(name):
+    """train_step differentiates all its loops as one node, step t of every loop as the streams of
+    one launch (engine.backward_batch).  Same gradients as replaying the loops one after another
+    (engine.backward), which is what the fallback does; and the batched path is the one taken."""
+    import ironcortex_amd as ic
+    gold, cfg, sd, tokens, focus = load_case(name)
+    grads, metrics = [], []
+    for force_loops in (False, True):
+        model = build(cfg, sd)
+        if force_loops:
+            model.engine._batch_uniform = lambda bt: False
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        seed_train()
+        out = ic.train_step(model, opt, tokens.to(DEV), ic.LossWeights(), torch.device(DEV))
+        c = model.engine.counters
+        if cfg.train_deterministic_inner_loop or cfg.B_br >= 1:
+            assert (c["loop_bwd"] > 0) == force_loops and (c["batch_bwd"] > 0) == (not force_loops), c
+        grads.append({n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()})
+        metrics.append(out)
+    assert {n for n, g in grads[0].items() if g is not None} == {n for n, g in grads[1].items() if g is not None}
+    for n, g in grads[0].items():
+        if g is not None:  # same kernels per (loop, step); only the order of the parameter-gradient sums differs
+            torch.testing.assert_close(g, grads[1][n], rtol=1e-4, atol=1e-6 * max(1.0, float(grads[1][n].abs().max())), msg=n)
+    for k in KEYS:
+        assert metrics[0][k] == pytest.approx(metrics[1][k], rel=1e-5, abs=1e-6), k
