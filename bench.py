@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("IC_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["IC_HANG_DUMP"]), exit=True)
     import ironcortex_amd as ic
     from ironcortex_amd import hip
 

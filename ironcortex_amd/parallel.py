@@ -48,9 +48,23 @@ class DataParallel:
         return torch.cat(parts, dim=0)
 
     def broadcast_module(self, module: torch.nn.Module, src: int = 0) -> None:
-        """Make replicas identical at start (parameters and persistent buffers)."""
+        """Make replicas identical at start (parameters and persistent buffers): one broadcast per
+        dtype over a packed copy, not one per tensor (the reference-shaped model exposes every edge
+        and region matrix as its own Parameter: ~1100 tensors at R=36)."""
+        by_dtype = {}
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data if isinstance(t, torch.nn.Parameter) else t, src=src, group=self.group)
+            t = t.data if isinstance(t, torch.nn.Parameter) else t
+            if t.numel() > 0:
+                by_dtype.setdefault((t.dtype, t.device), []).append(t)
+        for (dtype, _dev), ts in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
+            wire = torch.uint8 if dtype == torch.bool else dtype
+            flat = torch.cat([t.reshape(-1).to(wire) for t in ts])
+            dist.broadcast(flat, src=src, group=self.group)
+            views, off = [], 0
+            for t in ts:
+                views.append(flat[off:off + t.numel()].view(t.shape).to(dtype))
+                off += t.numel()
+            torch._foreach_copy_(ts, views)
 
     # ------------------------------------------------------------------ gradients
     def sync_grads(self, module: torch.nn.Module) -> None:
