@@ -130,6 +130,7 @@ class LoopEngine:
         self._in_cache = None
         self._pass = None  # accumulators of the backward pass in flight
         self._sess = None  # C structs shared by the loops between two reset()s
+        self._vhat0 = None  # critic value of the all-zero input state (same for every loop of a session)
         self._hs_ok = False
         self._fa_buf = None
         self._batch = None  # loops of one reasoning_loop_batch call, differentiated as ONE node
@@ -157,6 +158,7 @@ class LoopEngine:
         self._rescue_state()
         self.flush_units()
         self._sess = None
+        self._vhat0 = None
         self._hs_ok = False  # parameters may have moved since: _heads_setup checks every pointer again
         if self._arena is not None:
             self._arena.reset()
@@ -401,7 +403,8 @@ class LoopEngine:
         mask_of = lambda i: Mf[i0 + i] if i >= 0 else mask0[0]
         with torch.no_grad():
             best, last_step, traces = self._drive((step, front, region), in_ptrs, H_of, K_inner, dev, chunk, i0,
-                                                  trace_views=bool(m._logits_detached and grad))
+                                                  trace_views=bool(m._logits_detached and grad),
+                                                  zero_in=H_prev is getattr(m, "_zero_H", None))
         n = len(parent)
         last_logits = (chunk.fields["logits"][i0 + last_step] if last_step >= 0 else torch.zeros(m.V, device=dev))
         if not (m._logits_detached and grad):  # train_step stacks the loops' logits before the arena is reset
@@ -503,7 +506,7 @@ class LoopEngine:
         # per-branch scratch blocks are contiguous: branch b of a batched call uses block b
         # planner / critic scratch: one block per candidate branch (the chain runs for both branches
         # of an outer iteration before their scores say which one steers the next iteration)
-        buf = dict(ls=z(64), ws_prev=z(nb, d), motor=z(d), p_h=z(nb, d), p=z(nb, d), g_h=z(nb, 2 * d), g=z(nb, d),
+        buf = dict(ls=torch.zeros(64).pin_memory(), ws_prev=z(nb, d), motor=z(d), p_h=z(nb, d), p=z(nb, d), g_h=z(nb, 2 * d), g=z(nb, d),
                    c_h=z(nb, 2 * d),
                    z=z(nb, Kf + Kf * V), per_region=z(nb, R, V), probs=z(nb, V), aux=z(nb, 4), gsq=z(nb, 2 * R))
         P = {k: t.data_ptr() for k, t in buf.items()}
@@ -561,7 +564,7 @@ class LoopEngine:
                         tail=tail)
         return self._hs
 
-    def _drive(self, steps, in_ptrs, H_of, K_inner, dev, chunk, i0, trace_views=False):
+    def _drive(self, steps, in_ptrs, H_of, K_inner, dev, chunk, i0, trace_views=False, zero_in=False):
         """The control flow of reference model.py:329-460 over step ids, heads on the HIP library.
         Within an outer iteration the branches are chained only through the region state: their
         gate, router, heads and verifier run as one launch sequence with one stream per branch;
@@ -618,6 +621,9 @@ class LoopEngine:
             return True
 
         pairs_, tail_ = hs["pairs"], hs["tail"]
+        # ls is pinned host memory the kernels write directly (no device-to-host copy kernel in the
+        # loop's critical path): wait for the stream, then read it on the host
+        sync = torch.cuda.current_stream(dev).synchronize
         multi = L.ic_gemv_multi
 
         def verify(first: int, n: int, plan_too: bool) -> None:
@@ -662,6 +668,7 @@ class LoopEngine:
                 heads([cur], [par], [par])
                 traces.append(keep(H_of(cur)))
                 if k + 1 < K_inner:
+                    sync()
                     u_mean = float(ls[8])  # utils.py:127-130 of this step's logits (host sync)
             return cur, cur, traces
 
@@ -670,7 +677,11 @@ class LoopEngine:
         u_mean = 0.0
         planned = False  # True when the previous iteration already ran the planner for both candidates
         for k in range(K_inner):
-            if not planned:
+            if k == 0 and zero_in and self._vhat0 is not None:
+                # every loop of a train_step starts from the shared all-zero state: the planner's
+                # input (mean of the active rows: none) and so v_hat are the same as for the first loop
+                vals = None
+            elif not planned:
                 # planner / critic on the best candidate so far, chosen on the device (model.py:371-386)
                 sa.n_cand = len(branches)
                 for c, (_, hstep) in enumerate(branches):
@@ -681,8 +692,14 @@ class LoopEngine:
                 rc = steer_sel(sa_ref, st) or chain(steer, 6, st)
                 if rc:
                     check(rc, "ic_steer_select/ic_gemv_chain")
-            vals = ls.tolist()  # the one host sync of this outer iteration
-            v_hat = vals[40]
+            if k > 0 or not (zero_in and self._vhat0 is not None):
+                sync()
+                vals = ls.tolist()  # the one host sync of this outer iteration
+                v_hat = vals[40]
+                if k == 0 and zero_in:
+                    self._vhat0 = v_hat
+            else:
+                v_hat = self._vhat0
             if k > 0:
                 top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
                 if planned:
@@ -706,6 +723,7 @@ class LoopEngine:
             last = ids[-1]
             if should_halt(None, u_mean, k, K_inner):
                 break
+        sync()
         vals = ls.tolist()
         top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
         branches = [branches[i] for i in top]
