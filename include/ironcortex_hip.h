@@ -377,6 +377,10 @@ typedef struct ic_heads_args {
                                input for the NEXT outer iteration should this step win (model.py:344-349) */
 } ic_heads_args;
 int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
+/* The same, with one GEMV that only depends on the FIRST of the two launches (the first planner
+ * layer on ws_mean, heads.py:57) riding in the second: same results as ic_heads_fwd followed by
+ * ic_gemv_chain(g, 1). */
+int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t stream);
 
 /* The energy verifier chain (energy.py:12-30; last layer -> scalar energy) followed by the branch
  * score below, in the same launch when the chain is small. */

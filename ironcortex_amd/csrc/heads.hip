@@ -601,6 +601,20 @@ __global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a0) {
   logits_combine(heads_stream(a0, blockIdx.x), red);
 }
 
+// The combine of S streams next to ONE independent GEMV (the first planner layer, whose input
+// ic_heads_fwd's first launch wrote): blockIdx.z == 0 combines stream blockIdx.y, z == 1 is the GEMV.
+template <int NX>
+__global__ __launch_bounds__(256) void k_combine_gemv(ic_heads_args a0, ic_gemv_desc g, int S) {
+  if (blockIdx.z == 0) {
+    if (blockIdx.x != 0 || (int)blockIdx.y >= S) return;
+    __shared__ float red[4];
+    logits_combine(heads_stream(a0, blockIdx.y), red);
+    return;
+  }
+  if ((int)blockIdx.x * 8 >= g.rows || (int)blockIdx.y >= (g.nbatch > 1 ? g.nbatch : 1)) return;
+  gemv_reg_body<NX>(g, nullptr, nullptr);
+}
+
 __global__ void k_branch_score(const float* stats, const float* energy, float* score) {
   if (threadIdx.x == 0) score[0] = 0.6f * stats[2] + 0.2f * (-energy[0]) + 0.2f * stats[1];
 }
@@ -751,7 +765,19 @@ extern "C" int ic_verify_score(const ic_gemv_desc* descs, int32_t n, const float
   return IC_OK;
 }
 
-extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
+static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t stream);
+
+extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) { return heads_fwd(a, nullptr, stream); }
+
+extern "C" int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t stream) {
+  IC_REQUIRE(g != nullptr, "ic_heads_gemv_fwd: NULL descriptor");
+  int rc = check_gemv(*g, 0, "ic_heads_gemv_fwd");
+  if (rc) return rc;
+  IC_REQUIRE(g->n0 + g->n1 + g->n2 <= 1024, "ic_heads_gemv_fwd: %d input columns (need <= 1024)", g->n0 + g->n1 + g->n2);
+  return heads_fwd(a, g, stream);
+}
+
+static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t stream) {
   IC_REQUIRE(a != nullptr, "ic_heads_fwd: NULL args");
   IC_REQUIRE(a->R > 0 && a->V > 0 && a->Kf > 0 && a->Kf <= 16 && a->n_slots >= 0,
              "ic_heads_fwd: R=%d V=%d Kf=%d n_slots=%d", a->R, a->V, a->Kf, a->n_slots);
@@ -772,7 +798,15 @@ extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
   IC_DISPATCH_DCH(a->d, {
     IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 3 + a->R + (a->ws_mean ? 1 : 0), S), dim3(256), 0, st, *a));
   });
-  IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(S), dim3(256), 0, st, *a));
+  if (g) {
+    const int cols = g->n0 + g->n1 + g->n2, nb = g->nbatch > 1 ? g->nbatch : 1;
+    const dim3 grid(ic_ceil_div(g->rows, 8), nb > S ? nb : S, 2);
+    if (cols <= 256) IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_combine_gemv<4>, grid, dim3(256), 0, st, *a, *g, S));
+    else if (cols <= 512) IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_combine_gemv<8>, grid, dim3(256), 0, st, *a, *g, S));
+    else IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_combine_gemv<16>, grid, dim3(256), 0, st, *a, *g, S));
+  } else {
+    IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(S), dim3(256), 0, st, *a));
+  }
   IC_LAUNCH_CHECK("ic_heads_fwd");
   return IC_OK;
 }

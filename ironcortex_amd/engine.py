@@ -594,6 +594,7 @@ class LoopEngine:
         slots_ptr = lambda i, b: CP["slots"] + (i0 + i) * CS["slots"] if i >= 0 else s0p + b * n_slots * d * 4
         lsp = P["ls"]
         heads_fwd, chain, vscore, steer_sel = L.ic_heads_fwd, L.ic_gemv_chain, L.ic_verify_score, L.ic_steer_select
+        heads_gemv = L.ic_heads_gemv_fwd
 
         def heads(ids: List[int], pars: List[int], slots_from: List[int]) -> bool:
             """Workspace write + logits + statistics of the consecutive steps ids (one launch
@@ -615,7 +616,11 @@ class LoopEngine:
             ha.surprise = CP["surprise_o"] + a * CS["surprise_o"] if afd else None
             ha.logits = CP["logits"] + a * CS["logits"]
             ha.stats = lsp + 8 * 4
-            rc = heads_fwd(ha_ref, st)
+            if ha.ws_mean:  # the first planner layer rides in the combine's launch (see verify())
+                steer[0].nbatch = n
+                rc = heads_gemv(ha_ref, ctypes.byref(steer[0]), st)
+            else:
+                rc = heads_fwd(ha_ref, st)
             if rc:
                 check(rc, "ic_heads_fwd")
             return True
@@ -630,8 +635,8 @@ class LoopEngine:
             """Verifier energy + branch score of n consecutive steps (batched layers).  plan_too: the
             planner -> critic chain of the NEXT outer iteration runs for all n candidates in the same
             launches (its input, the mean of each step's active rows, was written by the heads): the
-            first three layers ride with the verifier's, the rest follow; the host picks the winner's
-            v_hat once the scores are read."""
+            first layer rode with the heads' combine, the next three ride with the verifier's, the rest
+            follow; the host picks the winner's v_hat once the scores are read."""
             ver[0].x0 = CP["H"] + (i0 + first) * CS["H"] + motor * d * 4
             ver[2].y = lsp + 48 * 4
             for g in ver:
@@ -643,14 +648,14 @@ class LoopEngine:
                 return
             for g in steer:
                 g.nbatch = n
-            for i_ in range(3):
-                pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_]
+            for i_ in range(3):  # planner layer 0 already ran next to the heads' combine
+                pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_ + 1]
                 rc = multi(pairs_[i_], 2, lsp + 8 * 4, lsp if i_ == 2 else None, st)
                 if rc:
                     check(rc, "ic_gemv_multi")
-            for i_ in range(3):
-                tail_[i_] = steer[3 + i_]
-            rc = chain(tail_, 3, st)
+            for i_ in range(2):
+                tail_[i_] = steer[4 + i_]
+            rc = chain(tail_, 2, st)
             if rc:
                 check(rc, "ic_gemv_chain")
 

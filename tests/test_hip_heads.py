@@ -229,7 +229,9 @@ def test_strided_streams_equal_separate_calls():
     slots_in = torch.randn(2, 8, d, generator=g).to(DEV)
     sur = torch.rand(2, R, generator=g).to(DEV)
 
-    def run_heads(S, first, hp, hps, sp, sps):
+    steer = hs_["steer"]
+
+    def run_heads(S, first, hp, hps, sp, sps, plan=False):
         o = dict(slots=torch.zeros(S, 8, d, device=DEV), logits=torch.zeros(S, V, device=DEV))
         ls = torch.zeros(64, device=DEV)
         ha.S, ha.Hpar_sstride, ha.slots_in_sstride = S, hps, sps
@@ -237,7 +239,17 @@ def test_strided_streams_equal_separate_calls():
         ha.H_par, ha.slots_in = hp, sp
         ha.slots_out, ha.logits, ha.stats = o["slots"].data_ptr(), o["logits"].data_ptr(), ls.data_ptr() + 32
         ha.aux_surprise = buf["aux"].data_ptr() + 4
-        hip.check(L.ic_heads_fwd(ctypes.byref(ha), st), "heads")
+        ha.ws_mean = buf["ws_prev"].data_ptr()  # each stream's planner input comes out of the first launch
+        buf["ws_prev"].zero_(); buf["p_h"].zero_()
+        steer[0].nbatch = S
+        if plan:  # the first planner layer rides in the combine's launch
+            hip.check(L.ic_heads_gemv_fwd(ctypes.byref(ha), ctypes.byref(steer[0]), st), "heads+gemv")
+        else:
+            hip.check(L.ic_heads_fwd(ctypes.byref(ha), st), "heads")
+            hip.check(L.ic_gemv_chain(steer, 1, st), "planner layer 0")
+        steer[0].nbatch = 0
+        ha.ws_mean = None
+        o["ws_prev"], o["p_h"] = buf["ws_prev"].clone(), buf["p_h"].clone()
         ver[0].x0 = Hc[first].data_ptr() + (R - 1) * d * 4
         ver[2].y = ls.data_ptr() + 48 * 4
         for g_ in ver:
@@ -248,6 +260,13 @@ def test_strided_streams_equal_separate_calls():
         return o
 
     both = run_heads(2, 0, H2[1].data_ptr(), -R * d, slots_in[1].data_ptr(), -8 * d)
+    rode = run_heads(2, 0, H2[1].data_ptr(), -R * d, slots_in[1].data_ptr(), -8 * d, plan=True)
+    for k in both:
+        assert torch.equal(both[k], rode[k]), ("ic_heads_gemv_fwd != ic_heads_fwd + ic_gemv_chain", k)
+    on = mk.bool()
+    for b_ in range(2):  # ws_mean == mean of the active rows (model.py:344-349)
+        close(both["ws_prev"][b_], Hc[b_][on[b_]].mean(0).cpu(), what="ws_mean")
+    assert float(both["p_h"].abs().max()) > 0
     for s_, src in ((0, 1), (1, 0)):
         # single call for step s_ (its scratch is block 0, its statistics land at ls[8:12], score ls[0])
         ha_H, ha_m, ha_s = Hc[s_], mk[s_], sur[s_]
@@ -343,12 +362,13 @@ def test_planner_for_both_candidates_in_the_verifier_launches():
         for g_ in list(ver) + list(steer):
             g_.nbatch = 2
         if merged:
+            hip.check(L.ic_gemv_chain(steer, 1, st), "planner layer 0 (rides with the heads' combine in the engine)")
             for i in range(3):
-                pairs[i][0], pairs[i][1] = ver[i], steer[i]
+                pairs[i][0], pairs[i][1] = ver[i], steer[i + 1]
                 hip.check(L.ic_gemv_multi(pairs[i], 2, ls.data_ptr() + 32, ls.data_ptr() if i == 2 else None, st), "multi")
-            for i in range(3):
-                tail[i] = steer[3 + i]
-            hip.check(L.ic_gemv_chain(tail, 3, st), "tail")
+            for i in range(2):
+                tail[i] = steer[4 + i]
+            hip.check(L.ic_gemv_chain(tail, 2, st), "tail")
         else:
             hip.check(L.ic_verify_score(ver, 3, ls.data_ptr() + 32, ls.data_ptr(), st), "verify")
             hip.check(L.ic_gemv_chain(steer, 6, st), "chain")
