@@ -66,6 +66,13 @@ def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
         "region_rkv_bwd": st["u_b"] * 3 * dd + st["n_b"] * (16 + (6 if afd else 0)) * vec,
         "region_out_bwd": st["u_b"] * dd + st["n_b"] * 4 * vec,
     }
+    if "e" in st:  # the kernel sweep also prices the router: e = distinct active edges, q = destinations
+        e, q, R, prec = st["e"], st.get("q", 0), st["R"], st.get("prec", False)
+        table.update({
+            "router_fwd": e * (dd + vec) + R * vec,
+            "router_edge_fwd": e * (2 * dd + 3 * vec) + q * (dd + 2 * vec),
+            "router_mat_bwd": e * ((2 if prec else 1) * dd + 4 * vec) + (q * (dd + 2 * vec) if prec else 0),
+        })
     return table.get(kernel, 0.0)
 
 

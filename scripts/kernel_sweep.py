@@ -80,7 +80,8 @@ def main():
                 uniq = int(mask.any(0).sum())
                 src_act = mask.bool()[:, router.src_idx]
                 e_uniq = int(src_act.any(0).sum())
-                st = dict(n=uniq, e=e_uniq, q=0, R=R, afd=False, prec=False)
+                pairs = int(mask.sum())
+                st = dict(u_f=uniq, n_f=pairs, u_b=uniq, n_b=pairs, e=e_uniq, q=0, R=R, afd=False, prec=False)
                 row = {"R": R, "S": S, "k": k, "d": d, "unique_regions": uniq, "unique_edges": e_uniq,
                        "weights_MiB": {"regions": R * 4 * d * d * 4 / 2**20, "W_edge": router.E * d * d * 4 / 2**20},
                        "kernels": {}}
