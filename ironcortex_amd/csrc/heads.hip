@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void k_gemv_coop(ChainArgs c) {
 //   1 + R        slots_out[j] = KWTA(slots_in[j] + H[j-th active region]) (model.py:300-306, heads.py:34-36)
 // and the last workgroup to finish combines: logits, softmax, steering statistics.
 template <int DCH>
-__device__ __forceinline__ void ws_write_rows(const ic_heads_args& a, int lane, int wave) {
-  const int j = blockIdx.x * 4 + wave;
+__device__ __forceinline__ void ws_write_rows(const ic_heads_args& a, int lane, int wave, const int xb) {
+  const int j = xb * 4 + wave;
   if (j >= a.n_slots) return;
   int found = -1, seen = 0;  // index of the (j+1)-th set bit of mask
   for (int base = 0; base < a.R && found < 0; base += 64) {
@@ -394,9 +394,8 @@ __device__ __forceinline__ void ws_write_rows(const ic_heads_args& a, int lane, 
 }
 
 template <int DCH>
-__device__ __forceinline__ void token_rows(const ic_heads_args& a, int lane, int wave) {
+__device__ __forceinline__ void token_rows(const ic_heads_args& a, int lane, int wave, const int grp, const int xb) {
   const int d = a.d;
-  const int grp = blockIdx.y;
   int rows;
   const float *W, *b, *x;
   float* y;
@@ -409,7 +408,8 @@ __device__ __forceinline__ void token_rows(const ic_heads_args& a, int lane, int
     if (r == a.motor_idx || !a.mask[r]) {
       // not part of the mean (model.py:314-317): zeros, so the combine can add all R rows
       // without a mask test in its load chain (x + 0 is exact)
-      const int v = blockIdx.x * 256 + threadIdx.x;
+      const int v = xb * 8 + (int)threadIdx.x;  // this block's 8 rows (threads 0..7)
+      if (threadIdx.x >= 8) return;
       if (v < a.V) a.per_region[(size_t)r * a.V + v] = 0.f;
       return;
     }
@@ -417,7 +417,7 @@ __device__ __forceinline__ void token_rows(const ic_heads_args& a, int lane, int
     W = a.rh_W + (size_t)r * a.V * d; b = a.rh_b + (size_t)r * a.V; x = a.H + (size_t)r * d;
     y = a.per_region + (size_t)r * a.V;
   }
-  const int row0 = blockIdx.x * 8 + wave * 2;
+  const int row0 = xb * 8 + wave * 2;
   if (row0 >= rows) return;
   RowFrag<DCH> xv, w[2];
   float bias[2] = {0.f, 0.f};
@@ -537,8 +537,8 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
 // combine stays a launch of its own.
 // sum of squares of row r of H and of H_par (goodness terms, utils.py:159-162), wave per row
 template <int DCH>
-__device__ __forceinline__ void sq_rows(const ic_heads_args& a, int lane, int wave) {
-  const int r = blockIdx.x * 4 + wave;
+__device__ __forceinline__ void sq_rows(const ic_heads_args& a, int lane, int wave, const int xb) {
+  const int r = xb * 4 + wave;
   if (r >= a.R) return;
   RowFrag<DCH> h1, h0;
   load_row(h1, a.H + (size_t)r * a.d, a.d, lane);
@@ -574,7 +574,6 @@ __device__ __forceinline__ ic_heads_args heads_stream(ic_heads_args a, int s) {
 
 // mean of the active rows of H (same arithmetic as k_steer_select): one workgroup per stream
 __device__ __forceinline__ void ws_mean_rows(const ic_heads_args& a) {
-  if (blockIdx.x != 0) return;
   float n_on = 0.f;
   for (int r = 0; r < a.R; ++r) n_on += a.mask[r] ? 1.0f : 0.0f;
   const float den = fmaxf(n_on, 1.0f);
@@ -586,14 +585,24 @@ __device__ __forceinline__ void ws_mean_rows(const ic_heads_args& a) {
   }
 }
 
+// 1-D grid, no idle workgroups: [token head: ceil(lm_rows/8)] [region heads: R x ceil(V/8)]
+// [workspace write: ceil(n_slots/4)] [row sums of squares: ceil(R/4)] [ws_mean: 1 if asked for]
 template <int DCH>
 __global__ __launch_bounds__(256) void k_heads(ic_heads_args a0) {
-  const ic_heads_args a = heads_stream(a0, blockIdx.z);
+  const ic_heads_args a = heads_stream(a0, blockIdx.y);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((int)blockIdx.y == a.R + 1) ws_write_rows<DCH>(a, lane, wave);
-  else if ((int)blockIdx.y == a.R + 2) sq_rows<DCH>(a, lane, wave);
-  else if ((int)blockIdx.y == a.R + 3) ws_mean_rows(a);
-  else token_rows<DCH>(a, lane, wave);
+  int b = blockIdx.x;
+  const int n_tok = (a.Kf + a.Kf * a.V + 7) / 8, n_rh = (a.V + 7) / 8;
+  if (b < n_tok) return token_rows<DCH>(a, lane, wave, 0, b);
+  b -= n_tok;
+  if (b < a.R * n_rh) return token_rows<DCH>(a, lane, wave, 1 + b / n_rh, b % n_rh);
+  b -= a.R * n_rh;
+  const int n_ws = (a.n_slots + 3) / 4;
+  if (b < n_ws) return ws_write_rows<DCH>(a, lane, wave, b);
+  b -= n_ws;
+  const int n_sq = (a.R + 3) / 4;
+  if (b < n_sq) return sq_rows<DCH>(a, lane, wave, b);
+  if (a.ws_mean) ws_mean_rows(a);
 }
 
 __global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a0) {
@@ -791,12 +800,10 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t 
   IC_REQUIRE(a->V <= 1024, "ic_heads_fwd: V=%d (need <= 1024)", a->V);
   const int S = a->S > 1 ? a->S : 1;
   IC_REQUIRE(S <= 64, "ic_heads_fwd: S=%d (need <= 64)", S);
-  const int lm_rows = a->Kf + a->Kf * a->V;
-  const int max_rows = lm_rows > a->V ? lm_rows : a->V;
-  int nx = ic_ceil_div(max_rows, 8);
-  if (ic_ceil_div(a->n_slots, 4) > nx) nx = ic_ceil_div(a->n_slots, 4);
+  const int nblk = ic_ceil_div(a->Kf + a->Kf * a->V, 8) + a->R * ic_ceil_div(a->V, 8) + ic_ceil_div(a->n_slots, 4) +
+                   ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0);
   IC_DISPATCH_DCH(a->d, {
-    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nx, 3 + a->R + (a->ws_mean ? 1 : 0), S), dim3(256), 0, st, *a));
+    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, S), dim3(256), 0, st, *a));
   });
   if (g) {
     const int cols = g->n0 + g->n1 + g->n2, nb = g->nbatch > 1 ? g->nbatch : 1;

@@ -28,6 +28,10 @@ opt.step = timed("opt.step", opt.step)
 orig_bwd = torch.Tensor.backward
 torch.Tensor.backward = timed("total.backward", orig_bwd)
 m.finalize_grads = timed("finalize_grads", m.finalize_grads)
+m.engine.backward_batch = timed("engine.backward_batch", m.engine.backward_batch)
+m._coord._end = timed("GradCoordinator._end (wgrad + per-pass reductions)", m._coord._end)
+m.engine.begin_batch = timed("engine.begin_batch", m.engine.begin_batch)
+m.engine.end_batch = timed("engine.end_batch", m.engine.end_batch)
 m.sensor_vectors_batch = timed("sensor_vectors_batch(mixer, batched)", m.sensor_vectors_batch)
 m.reasoning_loop_batch = timed("reasoning_loop_batch(total)", m.reasoning_loop_batch)
 opt.zero_grad = timed("opt.zero_grad", opt.zero_grad)
