@@ -501,12 +501,31 @@ __global__ __launch_bounds__(256) void k_region_fin_chain(ic_region_args a, floa
   const float* den_src = a.den + (size_t)r * d;
   const float* var_src = afd ? a.var + (size_t)r * d : nullptr;
   const float al = (float)a.pred_alpha;
+  // the rows a stream needs that do not depend on the chain (hpre + surprise terms when active,
+  // the message row when not) are requested one stream ahead
+  struct Pre {
+    RowFrag<DCH> h, st, m;
+    bool on;
+  };
+  auto fetch = [&](int s, Pre& p) {
+    const int row = s * a.R + r;
+    const size_t off = (size_t)row * d;
+    p.on = a.mask[row] != 0;
+    if (p.on) {
+      load_row(p.h, a.hpre + off, d, lane);
+      if (afd) load_row(p.st, a.sterm + off, d, lane);
+    } else if (pred) {
+      load_row(p.m, a.M + off, d, lane);
+    }
+  };
+  Pre cur, nxt;
+  fetch(0, cur);
   for (int s = 0; s < a.S; ++s) {
     const int row = s * a.R + r;
     const size_t off = (size_t)row * d;
-    if (a.mask[row]) {
-      RowFrag<DCH> h, out, g;
-      load_row(h, a.hpre + off, d, lane);
+    if (s + 1 < a.S) fetch(s + 1, nxt);
+    if (cur.on) {
+      RowFrag<DCH> h = cur.h, out, g;
       if (a.flags & IC_F_NOKWTA) {
         out = h;
 #pragma unroll
@@ -521,8 +540,7 @@ __global__ __launch_bounds__(256) void k_region_fin_chain(ic_region_args a, floa
         p = z;
       }
       if (afd) {
-        RowFrag<DCH> st;
-        load_row(st, a.sterm + off, d, lane);
+        const RowFrag<DCH>& st = cur.st;
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < DCH; ++j) sum += (st.v[j].x + st.v[j].y) + (st.v[j].z + st.v[j].w);
@@ -543,8 +561,7 @@ __global__ __launch_bounds__(256) void k_region_fin_chain(ic_region_args a, floa
       store_row(z, a.H + off, d, lane);
       RowFrag<DCH> t;
       if (pred) {
-        RowFrag<DCH> m;
-        load_row(m, a.M + off, d, lane);
+        const RowFrag<DCH>& m = cur.m;
 #pragma unroll
         for (int j = 0; j < DCH; ++j) {
           p.v[j].x = al * p.v[j].x + one_minus_alpha * m.v[j].x;
@@ -572,6 +589,7 @@ __global__ __launch_bounds__(256) void k_region_fin_chain(ic_region_args a, floa
         }
       }
     }
+    cur = nxt;
   }
 }
 
