@@ -454,8 +454,14 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
   float zg[KF];
 #pragma unroll
   for (int f = 0; f < KF; ++f) zg[f] = f < Kf ? a.z[f] : -INFINITY;
-  float nw = 0.f;
-  for (int r = 0; r < R; ++r) nw += (r != a.motor_idx && a.mask[r]) ? 1.0f : 0.0f;
+  // number of region heads in the mean: every lane tests its own regions (one round trip for
+  // R <= 64), the count comes from ballots -- an exact small integer either way
+  int nwi = 0;
+  for (int base = 0; base < R; base += 64) {
+    const int r = base + (tid & 63);
+    nwi += __popcll(__ballot(r < R && r != a.motor_idx && a.mask[r] != 0));
+  }
+  const float nw = (float)nwi;
   const int n = R * a.d;
   float g1 = 0.f, g0 = 0.f, sp = 0.f;
   for (int r = tid; r < R; r += 256) {  // row sums of squares from k_heads
@@ -517,11 +523,21 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
       pmax = fmaxf(pmax, p);
     }
   }
-  clp = block_sum(clp, red);
-  pmax = block_max(pmax, red);
-  g1 = block_sum(g1, red);
-  g0 = block_sum(g0, red);
-  sp = block_sum(sp, red) / (float)R;
+  {  // the five closing reductions share one pair of barriers (same summation order as block_sum)
+    __shared__ float red5[5][4];
+    const int lane = tid & 63, wave = tid >> 6;
+    const float v0 = wave_sum(clp), v1 = wave_max(pmax), v2 = wave_sum(g1), v3 = wave_sum(g0), v4 = wave_sum(sp);
+    __syncthreads();
+    if (lane == 0) {
+      red5[0][wave] = v0; red5[1][wave] = v1; red5[2][wave] = v2; red5[3][wave] = v3; red5[4][wave] = v4;
+    }
+    __syncthreads();
+    clp = (red5[0][0] + red5[0][1]) + (red5[0][2] + red5[0][3]);
+    pmax = fmaxf(fmaxf(red5[1][0], red5[1][1]), fmaxf(red5[1][2], red5[1][3]));
+    g1 = (red5[2][0] + red5[2][1]) + (red5[2][2] + red5[2][3]);
+    g0 = (red5[3][0] + red5[3][1]) + (red5[3][2] + red5[3][3]);
+    sp = ((red5[4][0] + red5[4][1]) + (red5[4][2] + red5[4][3])) / (float)R;
+  }
   if (tid == 0) {
     a.stats[0] = 1.0f - pmax;
     a.stats[1] = clp;
