@@ -377,10 +377,14 @@ typedef struct ic_heads_args {
                                input for the NEXT outer iteration should this step win (model.py:344-349) */
 } ic_heads_args;
 int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
-/* The same, with one GEMV that only depends on the FIRST of the two launches (the first planner
- * layer on ws_mean, heads.py:57) riding in the second: same results as ic_heads_fwd followed by
- * ic_gemv_chain(g, 1). */
-int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t stream);
+/* The same, with up to two GEMVs riding in its two launches (either may be NULL):
+ *   g_mean  takes the mean of each stream's active rows of H as its d-column input (the first planner
+ *           layer, heads.py:57 on model.py:344-349; nbatch must equal S) and rides in the FIRST launch;
+ *           bit-identical to ws_mean followed by ic_gemv_chain(g_mean, 1);
+ *   g_next  any GEMV that only depends on the first launch, rides in the second (the combine's).
+ */
+int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g_mean, const ic_gemv_desc* g_next,
+                      ic_stream_t stream);
 
 /* The energy verifier chain (energy.py:12-30; last layer -> scalar energy) followed by the branch
  * score below, in the same launch when the chain is small. */

@@ -595,16 +595,86 @@ __device__ __forceinline__ void ws_mean_rows(const ic_heads_args& a) {
   const float den = fmaxf(n_on, 1.0f);
   for (int c = threadIdx.x; c < a.d; c += 256) {
     float s = 0.f;
-    for (int r = 0; r < a.R; ++r)
-      if (a.mask[r]) s += a.H[(size_t)r * a.d + c];
+    for (int r0 = 0; r0 < a.R; r0 += 8) {  // 8 rows in flight, added in row order if active
+      float v[8];
+      bool on[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) on[u] = r0 + u < a.R && a.mask[r0 + u] != 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r0 + u < a.R ? a.H[(size_t)(r0 + u) * a.d + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (on[u]) s += v[u];
+    }
     a.ws_mean[c] = s / den;
+  }
+}
+
+// A GEMV whose input IS the mean of the active rows of H (the first planner layer, heads.py:57 on
+// model.py:344-349): every wave forms the mean in its own lanes' columns -- same order of
+// additions as ws_mean_rows, same dot-product order as k_gemv_reg, so the result is bit-identical
+// to ws_mean_rows followed by k_gemv_reg -- and needs no launch after the one that wrote H.
+template <int NX>
+__device__ __forceinline__ void gemv_on_ws_mean(const ic_heads_args& a, const ic_gemv_desc& g, const int xb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cols = a.d;
+  const int row0 = xb * 8 + wave * 2;
+  if (row0 >= g.rows) return;
+  const bool two = row0 + 1 < g.rows;
+  float xr[NX], w0[NX], w1[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int c = lane + 64 * i;
+    w0[i] = c < cols ? g.W[(size_t)row0 * cols + c] : 0.f;
+    w1[i] = (two && c < cols) ? g.W[(size_t)(row0 + 1) * cols + c] : 0.f;
+    xr[i] = 0.f;
+  }
+  const float b0 = g.b ? g.b[row0] : 0.f, b1 = (g.b && two) ? g.b[row0 + 1] : 0.f;
+  float n_on = 0.f;
+  for (int r = 0; r < a.R; ++r) n_on += a.mask[r] ? 1.0f : 0.0f;
+  const float den = fmaxf(n_on, 1.0f);
+  // rows are requested UB at a time whether active or not (L2 hits), then added in row order if
+  // active: one memory round trip per UB rows instead of two per active row
+  constexpr int UB = NX <= 4 ? 8 : (NX <= 8 ? 4 : 2);
+  for (int r0 = 0; r0 < a.R; r0 += UB) {
+    float v[UB][NX];
+    bool on[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) on[u] = r0 + u < a.R && a.mask[r0 + u] != 0;
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int c = lane + 64 * i;
+        v[u][i] = (r0 + u < a.R && c < cols) ? a.H[(size_t)(r0 + u) * a.d + c] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (on[u]) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xr[i] += v[u][i];
+      }
+  }
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const float v = xr[i] / den;
+    a0 = fmaf(w0[i], v, a0);
+    a1 = fmaf(w1[i], v, a1);
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if (lane == 0) {
+    g.y[row0] = apply_act(a0 + b0, g.act);
+    if (two) g.y[row0 + 1] = apply_act(a1 + b1, g.act);
   }
 }
 
 // 1-D grid, no idle workgroups: [token head: ceil(lm_rows/8)] [region heads: R x ceil(V/8)]
 // [workspace write: ceil(n_slots/4)] [row sums of squares: ceil(R/4)] [ws_mean: 1 if asked for]
+// [a GEMV on that mean: ceil(rows/8) if asked for]
 template <int DCH>
-__global__ __launch_bounds__(256) void k_heads(ic_heads_args a0) {
+__global__ __launch_bounds__(256) void k_heads(ic_heads_args a0, ic_gemv_desc g0, int n_g) {
   const ic_heads_args a = heads_stream(a0, blockIdx.y);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int b = blockIdx.x;
@@ -618,7 +688,12 @@ __global__ __launch_bounds__(256) void k_heads(ic_heads_args a0) {
   b -= n_ws;
   const int n_sq = (a.R + 3) / 4;
   if (b < n_sq) return sq_rows<DCH>(a, lane, wave, b);
-  if (a.ws_mean) ws_mean_rows(a);
+  b -= n_sq;
+  if (a.ws_mean) {
+    if (b == 0) return ws_mean_rows(a);
+    b -= 1;
+  }
+  if (b < n_g) gemv_on_ws_mean<4 * DCH>(a, gemv_batch(g0, blockIdx.y), b);
 }
 
 __global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a0) {
@@ -790,19 +865,32 @@ extern "C" int ic_verify_score(const ic_gemv_desc* descs, int32_t n, const float
   return IC_OK;
 }
 
-static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t stream);
+static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_gemv_desc* g, ic_stream_t stream);
 
-extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) { return heads_fwd(a, nullptr, stream); }
+extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) { return heads_fwd(a, nullptr, nullptr, stream); }
 
-extern "C" int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t stream) {
-  IC_REQUIRE(g != nullptr, "ic_heads_gemv_fwd: NULL descriptor");
-  int rc = check_gemv(*g, 0, "ic_heads_gemv_fwd");
-  if (rc) return rc;
-  IC_REQUIRE(g->n0 + g->n1 + g->n2 <= 1024, "ic_heads_gemv_fwd: %d input columns (need <= 1024)", g->n0 + g->n1 + g->n2);
-  return heads_fwd(a, g, stream);
+extern "C" int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g_mean, const ic_gemv_desc* g_next,
+                                 ic_stream_t stream) {
+  IC_REQUIRE(a != nullptr, "ic_heads_gemv_fwd: NULL args");
+  if (g_mean) {
+    IC_REQUIRE(g_mean->W && g_mean->y && g_mean->rows > 0, "ic_heads_gemv_fwd: g_mean has NULL W/y or no rows");
+    IC_REQUIRE(g_mean->n0 == a->d && g_mean->n1 == 0 && g_mean->n2 == 0 && !g_mean->ln_g,
+               "ic_heads_gemv_fwd: g_mean must take exactly the d=%d columns of the mean (n0=%d n1=%d n2=%d)", a->d,
+               g_mean->n0, g_mean->n1, g_mean->n2);
+    IC_REQUIRE((g_mean->nbatch > 1 ? g_mean->nbatch : 1) == (a->S > 1 ? a->S : 1),
+               "ic_heads_gemv_fwd: g_mean.nbatch=%d must equal the number of streams %d", g_mean->nbatch, a->S);
+    IC_REQUIRE(g_mean->act >= IC_ACT_NONE && g_mean->act <= IC_ACT_SILU, "ic_heads_gemv_fwd: act=%d", g_mean->act);
+  }
+  if (g_next) {
+    int rc = check_gemv(*g_next, 0, "ic_heads_gemv_fwd");
+    if (rc) return rc;
+    IC_REQUIRE(g_next->n0 + g_next->n1 + g_next->n2 <= 1024, "ic_heads_gemv_fwd: %d input columns (need <= 1024)",
+               g_next->n0 + g_next->n1 + g_next->n2);
+  }
+  return heads_fwd(a, g_mean, g_next, stream);
 }
 
-static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t stream) {
+static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_gemv_desc* g, ic_stream_t stream) {
   IC_REQUIRE(a != nullptr, "ic_heads_fwd: NULL args");
   IC_REQUIRE(a->R > 0 && a->V > 0 && a->Kf > 0 && a->Kf <= 16 && a->n_slots >= 0,
              "ic_heads_fwd: R=%d V=%d Kf=%d n_slots=%d", a->R, a->V, a->Kf, a->n_slots);
@@ -816,10 +904,12 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* g, ic_stream_t 
   IC_REQUIRE(a->V <= 1024, "ic_heads_fwd: V=%d (need <= 1024)", a->V);
   const int S = a->S > 1 ? a->S : 1;
   IC_REQUIRE(S <= 64, "ic_heads_fwd: S=%d (need <= 64)", S);
+  const int n_g = gm ? ic_ceil_div(gm->rows, 8) : 0;
   const int nblk = ic_ceil_div(a->Kf + a->Kf * a->V, 8) + a->R * ic_ceil_div(a->V, 8) + ic_ceil_div(a->n_slots, 4) +
-                   ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0);
+                   ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0) + n_g;
+  ic_gemv_desc g_none = {};
   IC_DISPATCH_DCH(a->d, {
-    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, S), dim3(256), 0, st, *a));
+    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, S), dim3(256), 0, st, *a, gm ? *gm : g_none, n_g));
   });
   if (g) {
     const int cols = g->n0 + g->n1 + g->n2, nb = g->nbatch > 1 ? g->nbatch : 1;

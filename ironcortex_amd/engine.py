@@ -616,9 +616,9 @@ class LoopEngine:
             ha.surprise = CP["surprise_o"] + a * CS["surprise_o"] if afd else None
             ha.logits = CP["logits"] + a * CS["logits"]
             ha.stats = lsp + 8 * 4
-            if ha.ws_mean:  # the first planner layer rides in the combine's launch (see verify())
-                steer[0].nbatch = n
-                rc = heads_gemv(ha_ref, ctypes.byref(steer[0]), st)
+            if ha.ws_mean:  # the first two planner layers ride in the heads' two launches (see verify())
+                steer[0].nbatch = steer[1].nbatch = n
+                rc = heads_gemv(ha_ref, ctypes.byref(steer[0]), ctypes.byref(steer[1]), st)
             else:
                 rc = heads_fwd(ha_ref, st)
             if rc:
@@ -635,8 +635,8 @@ class LoopEngine:
             """Verifier energy + branch score of n consecutive steps (batched layers).  plan_too: the
             planner -> critic chain of the NEXT outer iteration runs for all n candidates in the same
             launches (its input, the mean of each step's active rows, was written by the heads): the
-            first layer rode with the heads' combine, the next three ride with the verifier's, the rest
-            follow; the host picks the winner's v_hat once the scores are read."""
+            first two layers rode in the heads' two launches, the next three ride with the verifier's, the
+            last follows; the host picks the winner's v_hat once the scores are read."""
             ver[0].x0 = CP["H"] + (i0 + first) * CS["H"] + motor * d * 4
             ver[2].y = lsp + 48 * 4
             for g in ver:
@@ -648,14 +648,13 @@ class LoopEngine:
                 return
             for g in steer:
                 g.nbatch = n
-            for i_ in range(3):  # planner layer 0 already ran next to the heads' combine
-                pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_ + 1]
+            for i_ in range(3):  # planner layers 0 and 1 already ran inside the heads' two launches
+                pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_ + 2]
                 rc = multi(pairs_[i_], 2, lsp + 8 * 4, lsp if i_ == 2 else None, st)
                 if rc:
                     check(rc, "ic_gemv_multi")
-            for i_ in range(2):
-                tail_[i_] = steer[4 + i_]
-            rc = chain(tail_, 2, st)
+            tail_[0] = steer[5]
+            rc = chain(tail_, 1, st)
             if rc:
                 check(rc, "ic_gemv_chain")
 

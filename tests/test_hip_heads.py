@@ -241,15 +241,16 @@ def test_strided_streams_equal_separate_calls():
         ha.aux_surprise = buf["aux"].data_ptr() + 4
         ha.ws_mean = buf["ws_prev"].data_ptr()  # each stream's planner input comes out of the first launch
         buf["ws_prev"].zero_(); buf["p_h"].zero_()
-        steer[0].nbatch = S
-        if plan:  # the first planner layer rides in the combine's launch
-            hip.check(L.ic_heads_gemv_fwd(ctypes.byref(ha), ctypes.byref(steer[0]), st), "heads+gemv")
+        buf["p"].zero_()
+        steer[0].nbatch = steer[1].nbatch = S
+        if plan:  # the first two planner layers ride in the two launches of the heads
+            hip.check(L.ic_heads_gemv_fwd(ctypes.byref(ha), ctypes.byref(steer[0]), ctypes.byref(steer[1]), st), "heads+gemv")
         else:
             hip.check(L.ic_heads_fwd(ctypes.byref(ha), st), "heads")
-            hip.check(L.ic_gemv_chain(steer, 1, st), "planner layer 0")
-        steer[0].nbatch = 0
+            hip.check(L.ic_gemv_chain(steer, 2, st), "planner layers 0, 1")
+        steer[0].nbatch = steer[1].nbatch = 0
         ha.ws_mean = None
-        o["ws_prev"], o["p_h"] = buf["ws_prev"].clone(), buf["p_h"].clone()
+        o["ws_prev"], o["p_h"], o["p"] = buf["ws_prev"].clone(), buf["p_h"].clone(), buf["p"].clone()
         ver[0].x0 = Hc[first].data_ptr() + (R - 1) * d * 4
         ver[2].y = ls.data_ptr() + 48 * 4
         for g_ in ver:
@@ -266,7 +267,7 @@ def test_strided_streams_equal_separate_calls():
     on = mk.bool()
     for b_ in range(2):  # ws_mean == mean of the active rows (model.py:344-349)
         close(both["ws_prev"][b_], Hc[b_][on[b_]].mean(0).cpu(), what="ws_mean")
-    assert float(both["p_h"].abs().max()) > 0
+    assert float(both["p_h"].abs().max()) > 0 and float(both["p"].abs().max()) > 0
     for s_, src in ((0, 1), (1, 0)):
         # single call for step s_ (its scratch is block 0, its statistics land at ls[8:12], score ls[0])
         ha_H, ha_m, ha_s = Hc[s_], mk[s_], sur[s_]
@@ -362,13 +363,12 @@ def test_planner_for_both_candidates_in_the_verifier_launches():
         for g_ in list(ver) + list(steer):
             g_.nbatch = 2
         if merged:
-            hip.check(L.ic_gemv_chain(steer, 1, st), "planner layer 0 (rides with the heads' combine in the engine)")
+            hip.check(L.ic_gemv_chain(steer, 2, st), "planner layers 0, 1 (ride in the heads' launches in the engine)")
             for i in range(3):
-                pairs[i][0], pairs[i][1] = ver[i], steer[i + 1]
+                pairs[i][0], pairs[i][1] = ver[i], steer[i + 2]
                 hip.check(L.ic_gemv_multi(pairs[i], 2, ls.data_ptr() + 32, ls.data_ptr() if i == 2 else None, st), "multi")
-            for i in range(2):
-                tail[i] = steer[4 + i]
-            hip.check(L.ic_gemv_chain(tail, 2, st), "tail")
+            tail[0] = steer[5]
+            hip.check(L.ic_gemv_chain(tail, 1, st), "tail")
         else:
             hip.check(L.ic_verify_score(ver, 3, ls.data_ptr() + 32, ls.data_ptr(), st), "verify")
             hip.check(L.ic_gemv_chain(steer, 6, st), "chain")
