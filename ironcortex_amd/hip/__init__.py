@@ -13,7 +13,8 @@ from typing import Dict, List, Tuple
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _REPO_DIR = os.path.dirname(_PKG_DIR)
-LIB_PATH = os.path.join(_PKG_DIR, "libironcortex_hip.so")
+# IC_LIB_PATH: another build of the same library (A/B timing of a kernel change on one box)
+LIB_PATH = os.environ.get("IC_LIB_PATH") or os.path.join(_PKG_DIR, "libironcortex_hip.so")
 HEADER_PATH = os.path.join(_REPO_DIR, "include", "ironcortex_hip.h")
 
 _SCALARS = {
