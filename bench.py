@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--seq", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-kernel-sweep", action="store_true")
     args = ap.parse_args()
 
     if os.environ.get("IC_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
@@ -251,6 +252,18 @@ def main():
             out["kernels_ms_per_step_source"] = ("HIP events on every library kernel during the last warm-up step"
                                                  if survey else "HIP events over the timed region")
         out["roofline"] = roof
+        # the same kernels where bytes, not launch latency, bound them (BASELINE configs[2], one point:
+        # R=512, k=32, S=8 streams, d=256, forward): HIP events on every launch, ~2 s
+        if world == 1 and not args.no_kernel_sweep and args.config == "10m":
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                from kernel_sweep import sweep
+                pt = next(iter(sweep([512], [32], [8], 256, 10, False)))
+                out["kernel_sweep"] = {"point": "R=512,k=32,S=8,d=256 forward (synthetic, BASELINE configs[2])",
+                                       "peak_GBs": HBM_PEAK_GBS,
+                                       "kernels": {k: v for k, v in pt["kernels"].items() if v["GBs"]}}
+            except Exception as e:  # never fail the headline line for the extra measurement
+                out["kernel_sweep"] = {"error": repr(e)}
         cb = None
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.config, B, T, 1234)

@@ -18,18 +18,10 @@ from ironcortex_amd.region import RegionBank, RWKVRegionCell  # noqa: E402
 from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--R", type=int, nargs="+", default=[64, 128, 256, 512])
-    ap.add_argument("--k", type=int, nargs="+", default=[4, 8, 16, 32])
-    ap.add_argument("--S", type=int, nargs="+", default=[1, 8])
-    ap.add_argument("--d", type=int, default=256)
-    ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--backward", action="store_true")
-    args = ap.parse_args()
-    dev = torch.device("cuda:0")
-    d = args.d
-    for R in args.R:
+def sweep(Rs, ks, Ss, d=256, iters=20, backward=False):
+    """Yields one dict per (R, S, k) point."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for R in Rs:
         torch.manual_seed(0)
         nb, coords = hex_neighbors(R), hex_axial_coords(R).to(dev)
         cells = [RWKVRegionCell(d, _shared_bank=True) for _ in range(R)]
@@ -39,8 +31,8 @@ def main():
         bank.to_device()
         router = Router(nb, d, R).to(dev)
         nin = torch.ones(d, device=dev)
-        for S in args.S:
-            for k in args.k:
+        for S in Ss:
+            for k in ks:
                 g = torch.Generator().manual_seed(0)
                 mask = torch.zeros(S, R, dtype=torch.uint8)
                 for s in range(S):
@@ -69,12 +61,13 @@ def main():
                             bank.phase(M, sensor, nin, mask, 0.5)
 
                 for _ in range(3):
-                    run(args.backward)
+                    run(backward)
                 torch.cuda.synchronize()
+                hip.prof_select("")
                 hip.prof_enable(True)
                 hip.prof_read()
-                for _ in range(args.iters):
-                    run(args.backward)
+                for _ in range(iters):
+                    run(backward)
                 prof = hip.prof_read()
                 hip.prof_enable(False)
                 uniq = int(mask.any(0).sum())
@@ -91,9 +84,22 @@ def main():
                     row["kernels"][name] = {"avg_us": round(us, 2), "alg_MB": round(ab / 1e6, 3),
                                             "GBs": round(ab / (us * 1e-6) / 1e9, 1) if ab else None,
                                             "frac": round(ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if ab else None}
-                print(json.dumps(row), flush=True)
+                yield row
         del bank, router, cells
         torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--R", type=int, nargs="+", default=[64, 128, 256, 512])
+    ap.add_argument("--k", type=int, nargs="+", default=[4, 8, 16, 32])
+    ap.add_argument("--S", type=int, nargs="+", default=[1, 8])
+    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--backward", action="store_true")
+    args = ap.parse_args()
+    for row in sweep(args.R, args.k, args.S, args.d, args.iters, args.backward):
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":

@@ -6,10 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-kernel-sweep"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 $R/bench.py $ARGS > $OUT/prof_ks.log 2>&1
 cp $(find /tmp/prof_ks -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
-PARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+PARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-kernel-sweep"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -- python3 $R/bench.py $PARGS > $OUT/prof_f.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -- python3 $R/bench.py $PARGS > $OUT/prof_w.log 2>&1
 python3 $R/scripts/pmc_traffic.py $(find /tmp/prof_f -name '*counter_collection.csv' | head -1) $(find /tmp/prof_w -name '*counter_collection.csv' | head -1) \
