@@ -641,16 +641,23 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
   // rows per workgroup in the GEMV kernels: 8 (many small workgroups: best when few regions are
   // active and the launch is latency-bound), 16 or 32 (deeper per-wave load queues: best when the
   // launch streams hundreds of MiB).  rows_fwd = 0 lets the library choose from the problem size.
-  int rpb = a->rows_fwd;
-  if (rpb == 0) rpb = 8;
-  IC_REQUIRE(rpb == 8 || rpb == 16 || rpb == 32, "ic_region_phase_fwd: rows_fwd=%d (need 0, 8, 16 or 32)", rpb);
+  // Measured on MI355X (profiles/, R=128/512, S=1/8/64): the r/k/v kernel is best at 8 rows at every size
+  // (3 matrices x 8 rows already keep 24 KB per workgroup in flight); the output projection, one
+  // matrix, wants 16 rows from R > 64 and 32 from R >= 256 (28 -> 22 us at R=512, S=8).
+  int rpb = a->rows_fwd, rpb_out = a->rows_fwd;
+  IC_REQUIRE(rpb == 0 || rpb == 8 || rpb == 16 || rpb == 32, "ic_region_phase_fwd: rows_fwd=%d (need 0, 8, 16 or 32)", rpb);
+  if (rpb == 0) {
+    rpb = 8;
+    rpb_out = a->R >= 256 ? 32 : (a->R > 64 ? 16 : 8);
+  }
   if (a->d > 256 && rpb > 16) rpb = 16;  // register budget at DCH >= 2
-  const dim3 gmat(ic_ceil_div(a->d, rpb), a->R);
+  if (a->d > 256 && rpb_out > 16) rpb_out = 16;
+  const dim3 gmat(ic_ceil_div(a->d, rpb), a->R), gout(ic_ceil_div(a->d, rpb_out), a->R);
   const float oma = (float)(1.0 - a->pred_alpha);
   const bool chain = a->flags & IC_F_CHAIN;
   IC_REQUIRE(!chain || a->S <= 64, "ic_region_phase_fwd: IC_F_CHAIN needs S <= 64 (S=%d)", a->S);
   const bool fuse = chain || (a->S <= 2 && a->R <= 64);  // prologue inside rkv (measured a loss at R = 512)
-#define IC_FWD_LAUNCH(PP)                                                                                   \
+#define IC_RKV_LAUNCH(PP)                                                                                   \
   IC_DISPATCH_DCH(a->d, {                                                                                   \
     if (chain) {                                                                                            \
       IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, true, true>), gmat, blk, 0, st, *a, oma));  \
@@ -660,17 +667,26 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
       IC_TIMED(IC_KID_region_pro, st, hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a));         \
       IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv<DCH, PP, false, false>), gmat, blk, 0, st, *a, oma)); \
     }                                                                                                       \
-    IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL((k_region_out<DCH, PP>), gmat, blk, 0, st, *a));     \
-    if (chain) {                                                                                            \
-      IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin_chain<DCH>, dim3(ic_ceil_div(a->R, 4)), blk, 0, st, *a, oma)); \
-    } else {                                                                                                \
-      IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma));    \
-    }                                                                                                       \
   })
-  if (rpb == 8) IC_FWD_LAUNCH(1);
-  else if (rpb == 16) IC_FWD_LAUNCH(2);
-  else IC_FWD_LAUNCH(4);
-#undef IC_FWD_LAUNCH
+#define IC_OUT_LAUNCH(PP)                                                                                   \
+  IC_DISPATCH_DCH(a->d, {                                                                                   \
+    IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL((k_region_out<DCH, PP>), gout, blk, 0, st, *a));     \
+  })
+  if (rpb == 8) IC_RKV_LAUNCH(1);
+  else if (rpb == 16) IC_RKV_LAUNCH(2);
+  else IC_RKV_LAUNCH(4);
+  if (rpb_out == 8) IC_OUT_LAUNCH(1);
+  else if (rpb_out == 16) IC_OUT_LAUNCH(2);
+  else IC_OUT_LAUNCH(4);
+#undef IC_RKV_LAUNCH
+#undef IC_OUT_LAUNCH
+  IC_DISPATCH_DCH(a->d, {
+    if (chain) {
+      IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin_chain<DCH>, dim3(ic_ceil_div(a->R, 4)), blk, 0, st, *a, oma));
+    } else {
+      IC_TIMED(IC_KID_region_fin, st, hipLaunchKernelGGL(k_region_fin<DCH>, grow, blk, 0, st, *a, oma));
+    }
+  });
   IC_LAUNCH_CHECK("ic_region_phase_fwd");
   return IC_OK;
 }
