@@ -20,8 +20,11 @@ __device__ __forceinline__ int stream_step(const ic_region_bwd_args& b) { return
 // with many streams and few regions the launch is bounded by the serial stream loop of a
 // workgroup, not by the weight rows it re-reads from L2.
 __device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int R, int r, int sk) {
-  for (int s = blockIdx.z; s < S; s += gridDim.z)
-    if (mask[(size_t)s * sk * R + r]) return true;
+  const int lane = threadIdx.x & 63;  // lanes test 64 of this workgroup's streams per round trip
+  for (int sc = blockIdx.z; sc < S; sc += 64 * gridDim.z) {
+    const int s = sc + lane * gridDim.z;
+    if (__ballot(s < S && mask[(size_t)s * sk * R + r] != 0)) return true;
+  }
   return false;
 }
 // wave-per-row kernels: local row index -> (stream, region, row in the spread-out arrays)

@@ -130,9 +130,16 @@ __global__ __launch_bounds__(256) void k_region_pro(ic_region_args a) {
   }
 }
 
+// Is region r active in any stream?  Every lane tests its own streams (64 per round trip) and
+// the answer is a ballot: with hundreds of regions most workgroups of a launch are idle, and how
+// fast they leave (one memory round trip, not one per stream) decides how soon the working ones
+// get their slots.
 __device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int R, int r) {
-  for (int s = 0; s < S; ++s)
-    if (mask[s * R + r]) return true;
+  const int lane = threadIdx.x & 63;
+  for (int sc = 0; sc < S; sc += 64) {
+    const int s = sc + lane;
+    if (__ballot(s < S && mask[(size_t)s * R + r] != 0)) return true;
+  }
   return false;
 }
 
