@@ -101,8 +101,8 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
   const size_t dd = (size_t)d * d;
   if (y < a.E) {
     const int e = y, src = a.src[e];
-    bool any = false;
-    for (int s = 0; s < a.S; ++s) any |= prev_on(a, s, src);
+    bool any = false;  // lanes test 64 streams per round trip: idle workgroups leave quickly
+    for (int sc = 0; sc < a.S && !any; sc += 64) any = __ballot(sc + lane < a.S && prev_on(a, sc + lane, src)) != 0;
     if (!any) return;
     const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
     const float* K = a.key_W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
@@ -576,8 +576,10 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   // block-uniform activity test
   const int sk = stream_step(b);
   bool any = false;  // streams are split over gridDim.z as in the region backward
-  for (int s = blockIdx.z; s < a.S; s += gridDim.z)
-    any |= is_q ? (b.tape_qact[(size_t)s * sk * a.R + r] != 0) : (prev_on(b, s, src));
+  for (int sc = blockIdx.z; sc < a.S && !any; sc += 64 * gridDim.z) {
+    const int s = sc + lane * gridDim.z;
+    any = __ballot(s < a.S && (is_q ? (b.tape_qact[(size_t)s * sk * a.R + r] != 0) : prev_on(b, s, src))) != 0;
+  }
   if (!any) return;
   const float* W = is_q ? a.query_W + (size_t)r * dd : a.W + (size_t)a.widx[e] * dd;
   const float* K = (!is_q && prec) ? a.key_W + (size_t)a.widx[e] * dd : nullptr;
