@@ -658,6 +658,7 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
     rpb_out = a->R >= 256 ? 32 : (a->R > 64 ? 16 : 8);
   }
   if (a->d > 256 && rpb > 16) rpb = 16;  // register budget at DCH >= 2
+  if (a->d > 512 && rpb > 8) rpb = 8;    // DCH = 4: 16 rows of three matrices would spill
   if (a->d > 256 && rpb_out > 16) rpb_out = 16;
   const dim3 gmat(ic_ceil_div(a->d, rpb), a->R), gout(ic_ceil_div(a->d, rpb_out), a->R);
   const float oma = (float)(1.0 - a->pred_alpha);
