@@ -140,3 +140,41 @@ def test_batched_backward_equals_loop_by_loop(name):
             torch.testing.assert_close(g, grads[1][n], rtol=1e-4, atol=1e-6 * max(1.0, float(grads[1][n].abs().max())), msg=n)
     for k in KEYS:
         assert metrics[0][k] == pytest.approx(metrics[1][k], rel=1e-5, abs=1e-6), k
+
+
+def test_early_halt_engine_equals_general_path(monkeypatch):
+    """Loops that halt early (utils.py:147-151; forced here at k >= 1 of K_inner = 3): the engine and the general
+    path agree, the planner is not run for an iteration that will not happen, and train_step falls
+    back to replaying the loops one after another (they no longer sit K slots apart)."""
+    import ironcortex_amd as ic
+    from ironcortex_amd import engine as E, model as M
+    halt = lambda scores, u_mean, k, K_inner: k >= 1
+    monkeypatch.setattr(E, "should_halt", halt)
+    monkeypatch.setattr(M, "should_halt", halt)
+    gold, cfg, sd, tokens, focus = load_case("allflags")
+    outs = []
+    for engine in (True, False):
+        model = build(cfg, sd)
+        model.engine.enabled = engine
+        with torch.no_grad():
+            H, m, logits, traces, en, ent = model.reasoning_loop_batch(tokens.to(DEV), cfg.K_inner, focus.to(DEV))
+        outs.append((H, m, logits, [len(t) for t in traces]))
+        assert cfg.K_inner == 3 and model.counters["inner_steps"] == tokens.shape[0] * 2 * cfg.B_br  # k = 0, 1
+    assert torch.equal(outs[0][1], outs[1][1]) and outs[0][3] == outs[1][3]
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-5)
+    grads = []
+    for engine in (True, False):
+        model = build(cfg, sd)
+        model.engine.enabled = engine
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        seed_train()
+        out = ic.train_step(model, opt, tokens.to(DEV), ic.LossWeights(), torch.device(DEV))
+        if engine:
+            assert model.engine.counters["loop_bwd"] > 0 and model.engine.counters["batch_bwd"] == 0
+        grads.append(({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, out))
+    assert set(grads[0][0]) == set(grads[1][0])
+    for n, g in grads[0][0].items():
+        torch.testing.assert_close(g, grads[1][0][n], rtol=2e-3, atol=2e-5 * max(1.0, float(g.abs().max())), msg=n)
+    for k in KEYS:
+        assert grads[0][1][k] == pytest.approx(grads[1][1][k], rel=1e-3, abs=1e-4), k
