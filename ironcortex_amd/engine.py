@@ -416,6 +416,15 @@ class LoopEngine:
         # before the arena is recycled (15 of 16 loops of a train_step never need the copy)
         li = i0 + n - 1
         f = chunk.fields
+        wgt_li = li
+        if n > 0 and grad and self._batch is not None and n < n_max:
+            # the loop halted early: the batched backward expects the state the NEXT loop starts from
+            # in the last slot of this loop's block (the slot before the next block)
+            lj = i0 + max(1, n_max) - 1
+            for ko in ("num_o", "den_o", "dt_o", "var_o", "surprise_o", "pred_o", "radius_o", "radius_var_o"):
+                if ko in f:
+                    f[ko][lj].copy_(f[ko][li])
+            li = lj
         if n > 0:
             bank.num, bank.den, bank.dt = f["num_o"][li:li + 1], f["den_o"][li:li + 1], f["dt_o"][li:li + 1]
             if afd:
@@ -425,7 +434,7 @@ class LoopEngine:
             if rt_:
                 bank.radius, bank.radius_var = f["radius_o"][li:li + 1], f["radius_var_o"][li:li + 1]
             if prec:
-                router._last_wgt = f["wgt"][li:li + 1, :E]
+                router._last_wgt = f["wgt"][wgt_li:wgt_li + 1, :E]
             self._state_in_arena = True
         if m._units is not None and E > 0 and n > 0:  # bench.py's device-side unit counters
             self._unit_log.append((chunk, i0, list(parent), mask0[0]))
@@ -971,18 +980,19 @@ class LoopEngine:
         return LoopBatchFn.apply(sensors, self.model.bank.anchor(sensors.device), self, bt)
 
     def _batch_uniform(self, bt) -> bool:
-        """True when the recorded loops sit n_max slots apart in one chunk, ran all their steps from
-        the shared all-zero input state, and share parameters, flags and schedule."""
+        """True when the recorded loops sit n_max slots apart in one chunk, started from the shared
+        all-zero input state, and share parameters, flags and schedule."""
         ss = bt["samples"]
         s0, K = ss[0], bt["n_max"]
         for j, s in enumerate(ss):
-            if s.chunk is not bt["chunk"] or s.i0 != bt["base"] + j * K or s.n != K or not s.zero_in:
-                return False
+            if s.chunk is not bt["chunk"] or s.i0 != bt["base"] + j * K or s.n > K or not s.zero_in:
+                return False  # (s.n < K: halted early; run() moved its final state to the block's last slot)
             if (s.flags, s.kwta_k, s.kwta_temp) != (s0.flags, s0.kwta_k, s0.kwta_temp):
                 return False
             if s.ebias.data_ptr() != s0.ebias.data_ptr() or s.norm_in_w is not s0.norm_in_w or s.keep[1] is not s0.keep[1]:
                 return False
-            if s.step_pos != s0.step_pos:
+            m_ = min(len(s.step_pos), len(s0.step_pos))
+            if s.step_pos[:m_] != s0.step_pos[:m_]:
                 return False
         return True
 
@@ -1067,11 +1077,12 @@ class LoopEngine:
             RB = {k: (rtape.buf[k].data_ptr(), rtape.buf[k].stride(0) * rtape.buf[k].element_size())
                   for k in rtape.buf}
             # where each stream's step reads its input states: the parent's slot (relative to base)
-            par = torch.tensor([s.parent for s in ss], dtype=torch.int64, device=dev)       # [S,K]
+            pars = [list(s.parent) + [-1] * (K - s.n) for s in ss]                           # halted loops: padded
+            par = torch.tensor(pars, dtype=torch.int64, device=dev)                           # [S,K]
             slot = torch.where((par >= 0) & live, lanes[:, None] * K + par, torch.full_like(par, -1))
             in_slot = slot.t().contiguous().to(torch.int32)                                   # [K,S]
             rtape.visited[rt0:rt0 + V].copy_((slot >= 0).reshape(V).to(_U8))
-            r_live = [any(p >= 0 for p in col) for col in zip(*[s.parent for s in ss])]       # host: per step
+            r_live = [any(p >= 0 for p in col) for col in zip(*pars)]                         # host: per step
 
         # ---- structs
         tables, rP, bP = s0.keep[1], s0.keep[2], s0.keep[3]
@@ -1136,9 +1147,10 @@ class LoopEngine:
             rb_ref = ctypes.byref(rb)
 
         side, have = "a", False
-        for t in range(K - 1, -1, -1):
+        step_pos = max((s.step_pos for s in ss), key=len)
+        for t in range(max(s.best for s in ss), -1, -1):  # steps after every loop's winner reach no loss
             bimg.load(b_rows[t])
-            b.f.step_pos = s0.step_pos[t]
+            b.f.step_pos = step_pos[t]
             other = "b" if side == "a" else "a"
             for g in gnames:
                 setattr(b, g + "_o", WP[f"{g}_{side}"] if have else None)
