@@ -588,19 +588,39 @@ __global__ __launch_bounds__(256) void k_wgrad_region(ic_wgrad_region_args a) {
   RowFrag<DCH> acc0, acc1, op;
   zero_frag(acc0);
   zero_frag(acc1);
-  const int SR = a.S * a.R;
+  // (slot, stream) pairs tested 64 at a time, contributing ones walked in order with the next
+  // pair's operands in flight (see k_wgrad_edge): same order of additions as a plain scan
   bool any = false;
-  for (int t = 0; t < a.T; ++t) {
-    if (!a.visited[t]) continue;
-    for (int s = 0; s < a.S; ++s) {
-      const size_t row = (size_t)t * SR + (size_t)s * a.R + r;
-      if (!a.mask[row]) continue;
-      any = true;
+  const int TS = a.T * a.S;
+  const float* opbase = jm < 3 ? a.tape_x : a.tape_o;
+  for (int base = 0; base < TS; base += 64) {
+    const int ts = base + lane;
+    unsigned long long act = __ballot(ts < TS && a.visited[ts / a.S] != 0 && a.mask[(size_t)ts * a.R + r] != 0);
+    if (!act) continue;
+    any = true;
+    RowFrag<DCH> nxt;
+    float g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f;
+    int cur = base + __ffsll((long long)act) - 1;
+    act &= act - 1;
+    {
+      const size_t row = (size_t)cur * a.R + r;
       const float* g = a.tape_g + (row * 4 + jm) * d;
-      const float g0 = g[row0], g1 = g[row0 + 1];
-      load_row(op, (jm < 3 ? a.tape_x : a.tape_o) + row * d, d, lane);
+      g0 = g[row0]; g1 = g[row0 + 1];
+      load_row(op, opbase + row * d, d, lane);
+    }
+    while (cur >= 0) {
+      const int nx = act ? base + __ffsll((long long)act) - 1 : -1;
+      act &= act - 1;
+      if (nx >= 0) {
+        const size_t row = (size_t)nx * a.R + r;
+        const float* g = a.tape_g + (row * 4 + jm) * d;
+        h0 = g[row0]; h1 = g[row0 + 1];
+        load_row(nxt, opbase + row * d, d, lane);
+      }
       axpy_frag(acc0, g0, op);
       axpy_frag(acc1, g1, op);
+      op = nxt; g0 = h0; g1 = h1;
+      cur = nx;
     }
   }
   if (!any) return;

@@ -698,17 +698,38 @@ __global__ __launch_bounds__(256) void k_wgrad_edge(ic_wgrad_edge_args a) {
   RowFrag<DCH> acc0, acc1, op;
   zero_frag(acc0);
   zero_frag(acc1);
+  // (slot, stream) pairs are tested 64 at a time (one lane each, one memory round trip) and the
+  // contributing ones walked in order from the ballot, the next pair's operands in flight while
+  // the current one is accumulated: same order of additions as a plain scan.
   bool any = false;
-  for (int t = 0; t < a.T; ++t) {
-    if (!a.visited[t]) continue;
-    for (int s = 0; s < a.S; ++s) {
-      const size_t gi = ((size_t)t * a.S + s) * n_g + y;
-      if (!a.tape_eact[gi]) continue;
-      any = true;
-      const float* g = a.tape_g + gi * d;
-      load_row(op, a.tape_H + (((size_t)t * a.S + s) * a.R + hrow) * d, d, lane);
-      axpy_frag(acc0, g[row0], op);
-      axpy_frag(acc1, g[row0 + 1], op);
+  const int TS = a.T * a.S;
+  for (int base = 0; base < TS; base += 64) {
+    const int ts = base + lane;
+    unsigned long long act =
+        __ballot(ts < TS && a.visited[ts / a.S] != 0 && a.tape_eact[(size_t)ts * n_g + y] != 0);
+    if (!act) continue;
+    any = true;
+    RowFrag<DCH> nxt;
+    float g0 = 0.f, g1 = 0.f, h0 = 0.f, h1 = 0.f;
+    int cur = base + __ffsll((long long)act) - 1;
+    act &= act - 1;
+    {
+      const float* g = a.tape_g + ((size_t)cur * n_g + y) * d;
+      g0 = g[row0]; g1 = g[row0 + 1];
+      load_row(op, a.tape_H + ((size_t)cur * a.R + hrow) * d, d, lane);
+    }
+    while (cur >= 0) {
+      const int nx = act ? base + __ffsll((long long)act) - 1 : -1;
+      act &= act - 1;
+      if (nx >= 0) {
+        const float* g = a.tape_g + ((size_t)nx * n_g + y) * d;
+        h0 = g[row0]; h1 = g[row0 + 1];
+        load_row(nxt, a.tape_H + ((size_t)nx * a.R + hrow) * d, d, lane);
+      }
+      axpy_frag(acc0, g0, op);
+      axpy_frag(acc1, g1, op);
+      op = nxt; g0 = h0; g1 = h1;
+      cur = nx;
     }
   }
   if (!any) return;
