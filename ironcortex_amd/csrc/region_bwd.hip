@@ -186,64 +186,97 @@ __global__ __launch_bounds__(256) void k_region_out_bwd(ic_region_bwd_args b, in
   }
   const bool rt = a.flags & IC_F_RT;
   const int SR = a.S * sk * a.R;
-  for (int s = blockIdx.z; s < a.S; s += gridDim.z) {
+  // This workgroup's streams (z, z + nz, ...) are tested 64 at a time and the active ones walked
+  // from the ballot; the next stream's operands (the y row, its norm and radius, and the wave's
+  // RPW incoming gradients, one per lane) are requested before the current one is reduced.
+  struct Ops {
+    RowFrag<DCH> op;
+    float nrm, scale, g;
+  };
+  auto request = [&](int s, Ops& o) {
     const int row = s * sk * a.R + r;
-    if (!a.mask[row]) continue;  // block-uniform
     const size_t off = (size_t)row * d;
-    RowFrag<DCH> op, acc;
-    load_row(op, a.y + off, d, lane);
-    float scale = 1.0f;
+    load_row(o.op, a.y + off, d, lane);
+    o.nrm = o.scale = 1.0f;
     if (rt) {
-      const float nrm = a.ynorm[row];
-      scale = a.radius_o[row];
-#pragma unroll
-      for (int j = 0; j < DCH; ++j) {
-        op.v[j].x /= nrm; op.v[j].y /= nrm; op.v[j].z /= nrm; op.v[j].w /= nrm;
-      }
+      o.nrm = a.ynorm[row];
+      o.scale = a.radius_o[row];
     }
-    zero_frag(acc);
-    float part_rt = 0.f;
+    const int ch = row0 + (lane < RPW ? lane : 0);
+    o.g = 0.f;
+    if (lane < RPW && ch < d)
+      o.g = fold ? (b.gH ? b.gH[off + ch] * a.gate[off + ch] : 0.f) : b.ghpre[off + ch];
+  };
+  const int nz = gridDim.z;
+  for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+    const int sl = sc + lane * nz;
+    unsigned long long act = __ballot(sl < a.S && a.mask[(size_t)sl * sk * a.R + r] != 0);
+    if (!act) continue;
+    Ops cur, nxt;
+    int s_cur = sc + (__ffsll((long long)act) - 1) * nz;
+    act &= act - 1;
+    request(s_cur, cur);
+    while (s_cur >= 0) {
+      const int s_nxt = act ? sc + (__ffsll((long long)act) - 1) * nz : -1;
+      act &= act - 1;
+      if (s_nxt >= 0) request(s_nxt, nxt);
+      const int row = s_cur * sk * a.R + r;
+      const size_t off = (size_t)row * d;
+      RowFrag<DCH> op = cur.op, acc;
+      const float scale = cur.scale;
+      if (rt) {
+        const float nrm = cur.nrm;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int ch = row0 + i;
-      if (ch < d) {  // wave-uniform
-        const float g = fold ? (b.gH ? b.gH[off + ch] * a.gate[off + ch] : 0.f) : b.ghpre[off + ch];
-        float gi = g;
-        if (rt) {
-          const float hd = wave_sum(dot_frag(wo[i], op));
-          part_rt += g * hd;
-          gi = scale * g;
+        for (int j = 0; j < DCH; ++j) {
+          op.v[j].x /= nrm; op.v[j].y /= nrm; op.v[j].z /= nrm; op.v[j].w /= nrm;
         }
-        if (lane == 0) b.tape_g[((size_t)row * 4 + 3) * d + ch] = gi;
-        axpy_frag(acc, gi, wo[i]);
       }
-    }
-    // cross-wave reduction of the partial W_o^T g
+      zero_frag(acc);
+      float part_rt = 0.f;
 #pragma unroll
-    for (int j = 0; j < DCH; ++j) {
-      float* p = &red[wave][256 * j + 4 * lane];
-      p[0] = acc.v[j].x; p[1] = acc.v[j].y; p[2] = acc.v[j].z; p[3] = acc.v[j].w;
-    }
-    if (lane == 0) red[wave][DCH * 256] = part_rt;
-    __syncthreads();
-    if (wave == 0) {
-      RowFrag<DCH> tot;
+      for (int i = 0; i < RPW; ++i) {
+        const int ch = row0 + i;
+        const float g = __shfl(cur.g, i, 64);
+        if (ch < d) {  // wave-uniform
+          float gi = g;
+          if (rt) {
+            const float hd = wave_sum(dot_frag(wo[i], op));
+            part_rt += g * hd;
+            gi = scale * g;
+          }
+          if (lane == 0) b.tape_g[((size_t)row * 4 + 3) * d + ch] = gi;
+          axpy_frag(acc, gi, wo[i]);
+        }
+      }
+      // cross-wave reduction of the partial W_o^T g
 #pragma unroll
       for (int j = 0; j < DCH; ++j) {
-        const int c = 256 * j + 4 * lane;
-        tot.v[j].x = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-        tot.v[j].y = (red[0][c + 1] + red[1][c + 1]) + (red[2][c + 1] + red[3][c + 1]);
-        tot.v[j].z = (red[0][c + 2] + red[1][c + 2]) + (red[2][c + 2] + red[3][c + 2]);
-        tot.v[j].w = (red[0][c + 3] + red[1][c + 3]) + (red[2][c + 3] + red[3][c + 3]);
+        float* p = &red[wave][256 * j + 4 * lane];
+        p[0] = acc.v[j].x; p[1] = acc.v[j].y; p[2] = acc.v[j].z; p[3] = acc.v[j].w;
       }
-      store_row(tot, b.slab + ((size_t)blockIdx.x * SR + row) * d, d, lane);
-      if (rt && lane == 0) {
-        const int q = DCH * 256;
-        b.slab_rt[(size_t)blockIdx.x * SR + row] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+      if (lane == 0) red[wave][DCH * 256] = part_rt;
+      __syncthreads();
+      if (wave == 0) {
+        RowFrag<DCH> tot;
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          const int c = 256 * j + 4 * lane;
+          tot.v[j].x = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+          tot.v[j].y = (red[0][c + 1] + red[1][c + 1]) + (red[2][c + 1] + red[3][c + 1]);
+          tot.v[j].z = (red[0][c + 2] + red[1][c + 2]) + (red[2][c + 2] + red[3][c + 2]);
+          tot.v[j].w = (red[0][c + 3] + red[1][c + 3]) + (red[2][c + 3] + red[3][c + 3]);
+        }
+        store_row(tot, b.slab + ((size_t)blockIdx.x * SR + row) * d, d, lane);
+        if (rt && lane == 0) {
+          const int q = DCH * 256;
+          b.slab_rt[(size_t)blockIdx.x * SR + row] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+        }
+        if (blockIdx.x == 0) store_row(op, b.tape_o + off, d, lane);
       }
-      if (blockIdx.x == 0) store_row(op, b.tape_o + off, d, lane);
+      __syncthreads();
+      cur = nxt;
+      s_cur = s_nxt;
     }
-    __syncthreads();
   }
 }
 
