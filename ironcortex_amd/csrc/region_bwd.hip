@@ -362,30 +362,64 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, in
   }
   const bool afd = a.flags & IC_F_AFD, vec = a.flags & IC_F_NOISE_VEC, rt = a.flags & IC_F_RT;
   const int SR = a.S * sk * a.R;
-  for (int s = blockIdx.z; s < a.S; s += gridDim.z) {
+  // lane l < RPW owns channel row0 + l; what depends on (region, channel) only is read once
+  const int chr = row0 + (lane < RPW ? lane : 0);
+  const bool valid = lane < RPW && chr < d;  // rotation pairs (even, odd lane) are valid together
+  const int ch = valid ? chr : 0;            // clamp loads
+  const float rd = a.raw_decay[(size_t)r * d + ch];
+  float pn_p = 0.f, on_p = 0.f;
+  if (afd) {
+    pn_p = vec ? a.pn_param[(size_t)r * d + ch] : a.pn_param[r];
+    on_p = vec ? a.on_param[(size_t)r * d + ch] : a.on_param[r];
+  }
+  const bool rot = ch < 2 * a.m_time;
+  const float th = rot ? a.step_pos * a.W_time[ch >> 1] : 0.f;
+  // Streams of this workgroup (z, z + nz, ...) are tested 64 at a time; the active ones are walked
+  // from the ballot with the next stream's per-channel operands (one batch of loads) in flight
+  // while the current stream is reduced.  Every wave sees the same ballot: barriers stay uniform.
+  struct Ops {
+    float num_in, den_in, rr, kk, vv, gno, gdo, var_in, gvo, t[8];
+    int dt;
+  };
+  auto request = [&](int s, Ops& o) {
     const int row = s * sk * a.R + r;
-    if (!a.mask[row]) continue;  // block-uniform
+    const size_t idx = (size_t)row * d + ch;
+    o.dt = a.dt[row];
+    o.num_in = a.num[idx]; o.den_in = a.den[idx];
+    o.rr = a.r_s[idx]; o.kk = a.k_s[idx]; o.vv = a.v_s[idx];
+    o.gno = b.gnum_o ? b.gnum_o[idx] : 0.f;
+    o.gdo = b.gden_o ? b.gden_o[idx] : 0.f;
+    o.var_in = o.gvo = 0.f;
+    if (afd) {
+      o.var_in = a.var[idx];
+      o.gvo = b.gvar_o ? b.gvar_o[idx] : 0.f;
+    }
+    if (!rt) {  // gy of this channel: the o-projection's slabs (first eight; the rest at use)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o.t[u] = u < nslab ? b.slab[((size_t)u * SR + row) * d + ch] : 0.f;
+    }
+  };
+  const int nz = gridDim.z;
+  for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+   const int sl = sc + lane * nz;
+   unsigned long long act = __ballot(sl < a.S && a.mask[(size_t)sl * sk * a.R + r] != 0);
+   if (!act) continue;
+   Ops cur, nxt;
+   int s_cur = sc + (__ffsll((long long)act) - 1) * nz;
+   act &= act - 1;
+   request(s_cur, cur);
+   while (s_cur >= 0) {
+    const int s_nxt = act ? sc + (__ffsll((long long)act) - 1) * nz : -1;
+    act &= act - 1;
+    if (s_nxt >= 0) request(s_nxt, nxt);
+    const int row = s_cur * sk * a.R + r;
     const size_t off = (size_t)row * d;
-    const float steps = (float)(a.dt[row] + 1);
+    const float steps = (float)(cur.dt + 1);
     RowFrag<DCH> acc;
-    {  // lane l < RPW owns channel row0 + l: every operand of the wave's rows in ONE batch of loads
-      const int chr = row0 + (lane < RPW ? lane : 0);
-      const bool valid = lane < RPW && chr < d;  // rotation pairs (even, odd lane) are valid together
-      const int ch = valid ? chr : 0;            // clamp loads
+    {
       const size_t idx = off + ch;
-      // ---- every per-channel operand is requested before the row-wide gy reduction below
-      const float rd = a.raw_decay[(size_t)r * d + ch];
-      const float num_in = a.num[idx], den_in = a.den[idx];
-      const float rr = a.r_s[idx], kk = a.k_s[idx], vv = a.v_s[idx];
-      const float gno = b.gnum_o ? b.gnum_o[idx] : 0.f;
-      const float gdo = b.gden_o ? b.gden_o[idx] : 0.f;
-      float pn_p = 0.f, on_p = 0.f, var_in = 0.f, gvo = 0.f;
-      if (afd) {
-        pn_p = vec ? a.pn_param[(size_t)r * d + ch] : a.pn_param[r];
-        on_p = vec ? a.on_param[(size_t)r * d + ch] : a.on_param[r];
-        var_in = a.var[idx];
-        gvo = b.gvar_o ? b.gvar_o[idx] : 0.f;
-      }
+      const float num_in = cur.num_in, den_in = cur.den_in, rr = cur.rr, kk = cur.kk, vv = cur.vv;
+      const float gno = cur.gno, gdo = cur.gdo, var_in = cur.var_in, gvo = cur.gvo;
       // ---- gy of this channel: the o-projection's slabs, reduced here (no launch of its own)
       float gy;
       if (rt) {
@@ -400,7 +434,10 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, in
         __syncthreads();
       } else {
         gy = 0.f;
-        for (int s0 = 0; s0 < nslab; s0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (u < nslab) gy += cur.t[u];
+        for (int s0 = 8; s0 < nslab; s0 += 8) {
           float t[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) t[u] = s0 + u < nslab ? b.slab[((size_t)(s0 + u) * SR + row) * d + ch] : 0.f;
@@ -472,8 +509,7 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, in
       // rotation backward (iron_rope.py:63-64)
       float g_vraw = g_v;
       const float g_vo = __shfl_xor(g_v, 1, 64);
-      if (ch < 2 * a.m_time) {
-        const float th = a.step_pos * a.W_time[ch >> 1];
+      if (rot) {
         const float c = cosf(th), sn = sinf(th);
         g_vraw = (lane & 1) ? (-g_vo * sn + g_v * c) : (g_v * c + g_vo * sn);
       }
@@ -519,6 +555,9 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, in
       store_row(tot, b.slab2 + ((size_t)blockIdx.x * SR + row) * d, d, lane);
     }
     __syncthreads();
+    cur = nxt;
+    s_cur = s_nxt;
+   }
   }
 }
 
