@@ -284,6 +284,15 @@ int ic_gate_fwd(const ic_gate_args* a, ic_stream_t stream);
  * in S, R, d.  Falls back to the two calls for R > 64 or E == 0. */
 int ic_front_fwd(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream);
 
+/* One whole inner step (reference model.py:254-283, forward_inner_step: gate -> router -> region
+ * bank): ic_front_fwd(g, ra) followed by ic_region_phase_fwd(a) on the same stream, same results
+ * bit for bit.  ra->M must be a->M and g->mask must be a->mask.  With precision routing, d <= 256,
+ * R <= 64 and IC_F_CHAIN the router's per-destination combine has no launch of its own: the
+ * region's r/k/v kernel forms each message row from the edge messages in its prologue (and writes
+ * M and the edge weights for the backward); otherwise exactly the two calls. */
+int ic_loop_step_fwd(const ic_gate_args* g, const ic_router_args* ra, const ic_region_args* a,
+                     ic_stream_t stream);
+
 /* ------------------------------------------------------------------ primitives
  * KWTA (utils.py:38-60) on `rows` rows of width d: threshold = k-th largest |x|,
  * ties keep extra units.  gate receives the multiplier (for the backward). */

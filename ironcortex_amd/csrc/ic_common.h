@@ -204,3 +204,7 @@ void ic_prof_end(int kid, hipStream_t st);
   } while (0)
 
 static inline int ic_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// library-internal: gate + router edge launch of ic_front_fwd, with or without the combine launch
+__attribute__((visibility("hidden"))) int ic_front_launch(const ic_gate_args* g, const ic_router_args* a,
+                                                          ic_stream_t stream, bool combine);

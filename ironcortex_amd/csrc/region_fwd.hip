@@ -8,6 +8,7 @@
 // rows (lane l holds columns 4l..4l+3 of each 256-column chunk => one 1 KiB coalesced
 // request per row per wave) and reduces dot products with wave64 xor-shuffles.
 #include "ic_common.h"
+#include "ic_route.h"
 #include "ic_kwta.h"
 
 namespace {
@@ -75,15 +76,19 @@ __device__ __forceinline__ void prologue_row(const ic_region_args& a, int row, i
 // IC_F_CHAIN: the trace and dt of region r as they stand when stream s starts, given the last
 // stream before s that had the region active (prev, -1: none).  Streams in between were
 // inactive: each is one trace EMA step on its own message row (region.py:140-146) and dt+1.
-template <int DCH>
+// ROUTED (ic_loop_step_fwd): the message rows are not read from M but from the workgroup's LDS
+// copy (mrows[s][d], combined from the edges' messages at the start of the kernel).
+template <int DCH, bool ROUTED>
 __device__ __forceinline__ void chain_prologue(const ic_region_args& a, int r, int s, int prev, int lane,
                                                float one_minus_alpha, RowFrag<DCH>& u1, RowFrag<DCH>& x,
-                                               float& inv0, float& inv1, float& steps) {
+                                               float& inv0, float& inv1, float& steps,
+                                               const float* mrows) {
   const int d = a.d;
   const bool norm_in = a.flags & IC_F_NORM_IN, pred = a.flags & IC_F_PRED;
   const bool io = norm_in && a.sensor && (r == a.sensor_idx || r == a.motor_idx);
   RowFrag<DCH> u, sv, win, p, w;
-  load_row(u, a.M + ((size_t)s * a.R + r) * d, d, lane);
+  if (ROUTED) load_row(u, mrows + s * d, d, lane);
+  else load_row(u, a.M + ((size_t)s * a.R + r) * d, d, lane);
   if (io) load_row(sv, a.sensor, d, lane);
   if (norm_in) load_row(win, a.norm_in_w, d, lane);
   load_row(w, a.norm_w + (size_t)r * d, d, lane);
@@ -97,7 +102,8 @@ __device__ __forceinline__ void chain_prologue(const ic_region_args& a, int r, i
   for (int q = prev + 1; q < s; ++q) {
     if (pred) {
       RowFrag<DCH> m;
-      load_row(m, a.M + ((size_t)q * a.R + r) * d, d, lane);
+      if (ROUTED) load_row(m, mrows + q * d, d, lane);
+      else load_row(m, a.M + ((size_t)q * a.R + r) * d, d, lane);
 #pragma unroll
       for (int j = 0; j < DCH; ++j) {
         p.v[j].x = al * p.v[j].x + one_minus_alpha * m.v[j].x;
@@ -151,14 +157,41 @@ __device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int 
 // CHAIN (IC_F_CHAIN, needs FUSE): the streams are consecutive steps of one state stream; the state
 // a stream starts from is what the previous active stream of this launch computed (registers) or,
 // before the first one, the input state [1,R,..].
-template <int DCH, int PP, bool FUSE, bool CHAIN>
-__global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a, float one_minus_alpha) {
+// ROUTED (ic_loop_step_fwd, needs CHAIN, S <= kRoutedStreams, d % 8 == 0): the router's
+// per-destination combine is part of this kernel instead of a launch of its own.  The waves of a
+// workgroup share the streams' combines (wave w: streams w, w+4, ...; all in flight together), leave
+// the message rows in LDS for the prologue, and workgroup 0 of every region also writes M and the
+// edge weights (the trace EMA of k_region_fin_chain and the backward read them).
+constexpr int kRoutedStreams = 16;
+
+template <int DCH, int PP, bool FUSE, bool CHAIN, bool ROUTED>
+__device__ __forceinline__ void region_rkv_body(const ic_region_args& a, float one_minus_alpha,
+                                                const ic_router_args& ra) {
+  __shared__ __align__(16) float mrows[ROUTED ? kRoutedStreams * 256 * DCH : 4];
   const int r = blockIdx.y;
-  if (!region_has_work(a.mask, a.S, a.R, r)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool work = region_has_work(a.mask, a.S, a.R, r);
+  auto combine_rows = [&]() {
+    if (ROUTED) {
+      // idle regions: only workgroup 0 (M and weights); working ones: every workgroup needs the rows
+      // of its active streams, and of the sat-out ones when the trace EMA runs over them
+      const bool wr = blockIdx.x == 0, pred = a.flags & IC_F_PRED;
+      for (int s = wave; s < a.S; s += 4) {
+        if (wr || (work && (pred || a.mask[s * a.R + r]))) {
+          RowFrag<DCH> m;
+          combine_row<DCH>(ra, s, r, lane, wr, m);
+          if (work) store_row(m, mrows + s * a.d, a.d, lane);
+        }
+      }
+    }
+  };
+  if (!work) {
+    combine_rows();
+    return;
+  }
   const int d = a.d;
   const int row0 = blockIdx.x * (8 * PP) + wave * (2 * PP);  // even: rotation pairs stay in one wave
-  if (row0 >= d) return;
+  if (!ROUTED && row0 >= d) return;  // (ROUTED: d % 8 == 0, and every wave reaches the barrier)
   const size_t dd = (size_t)d * d;
   const float* Wr = a.W + (size_t)r * 4 * dd;
   const float* Wk = Wr + dd;
@@ -199,6 +232,8 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a, float one_
       rs[p] = sinf(th);
     }
   }
+  combine_rows();  // (after the weight rows were requested)
+  if (ROUTED) __syncthreads();
   // Streams are walked 64 at a time from one ballot of the mask; the operands of the NEXT active
   // stream (x row, dt, and the state scalars lanes 0/1 update) are requested before the current
   // stream's dot products are reduced, so a stream costs one memory round trip, not three.
@@ -213,7 +248,7 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a, float one_
       RowFrag<DCH> u1;
       float inv0, inv1;
       if (CHAIN) {
-        chain_prologue(a, r, s, prev, lane, one_minus_alpha, u1, o.xv, inv0, inv1, o.steps);
+        chain_prologue<DCH, ROUTED>(a, r, s, prev, lane, one_minus_alpha, u1, o.xv, inv0, inv1, o.steps, mrows);
       } else {
         prologue_row(a, row, lane, u1, o.xv, inv0, inv1);
       }
@@ -314,6 +349,17 @@ __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a, float one_
       s_cur = s_nxt;
     }
   }
+}
+
+template <int DCH, int PP, bool FUSE, bool CHAIN>
+__global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a, float one_minus_alpha) {
+  ic_router_args none;  // never read (ROUTED = false)
+  region_rkv_body<DCH, PP, FUSE, CHAIN, false>(a, one_minus_alpha, none);
+}
+
+template <int DCH, int PP>
+__global__ __launch_bounds__(256) void k_region_rkv_routed(ic_region_args a, float one_minus_alpha, ic_router_args ra) {
+  region_rkv_body<DCH, PP, true, true, true>(a, one_minus_alpha, ra);
 }
 
 // ---------------------------------------------------------------- output projection (+ radial/tangential)
@@ -637,7 +683,8 @@ static int check_region_args(const ic_region_args* a, const char* who) {
   return IC_OK;
 }
 
-extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) {
+// ra != nullptr: routed r/k/v kernel (the caller checked that the path applies)
+static int region_phase_launch(const ic_region_args* a, const ic_router_args* ra, ic_stream_t stream) {
   int rc = check_region_args(a, "ic_region_phase_fwd");
   if (rc) return rc;
   IC_REQUIRE(a->H && a->num_o && a->den_o && a->dt_o, "ic_region_phase_fwd: NULL output pointer");
@@ -680,7 +727,9 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
   IC_DISPATCH_DCH(a->d, {                                                                                   \
     IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL((k_region_out<DCH, PP>), gout, blk, 0, st, *a));     \
   })
-  if (rpb == 8) IC_RKV_LAUNCH(1);
+  if (ra) {
+    IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv_routed<1, 1>), gmat, blk, 0, st, *a, oma, *ra));
+  } else if (rpb == 8) IC_RKV_LAUNCH(1);
   else if (rpb == 16) IC_RKV_LAUNCH(2);
   else IC_RKV_LAUNCH(4);
   if (rpb_out == 8) IC_OUT_LAUNCH(1);
@@ -697,6 +746,29 @@ extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) 
   });
   IC_LAUNCH_CHECK("ic_region_phase_fwd");
   return IC_OK;
+}
+
+extern "C" int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream) {
+  return region_phase_launch(a, nullptr, stream);
+}
+
+extern "C" int ic_loop_step_fwd(const ic_gate_args* g, const ic_router_args* ra, const ic_region_args* a,
+                                ic_stream_t stream) {
+  IC_REQUIRE(g != nullptr && ra != nullptr && a != nullptr, "ic_loop_step_fwd: NULL args");
+  // the combine rides in the region kernel when it is the wave-per-destination one (precision
+  // routing, d <= 256, in-degree <= 8 as for ic_router_fwd) and the streams are one state chain
+  const bool routed = (ra->flags & IC_RF_PRECISION) && ra->E > 0 && g->R <= 64 && a->d <= 256 && a->d >= 32 &&
+                      a->d % 8 == 0 && (a->flags & IC_F_CHAIN) && a->S <= kRoutedStreams &&
+                      (a->rows_fwd == 0 || a->rows_fwd == 8);
+  if (!routed) {
+    int rc = ic_front_fwd(g, ra, stream);
+    return rc ? rc : ic_region_phase_fwd(a, stream);
+  }
+  IC_REQUIRE(ra->S == a->S && ra->R == a->R && ra->d == a->d, "ic_loop_step_fwd: router (S=%d,R=%d,d=%d) and region (S=%d,R=%d,d=%d) disagree",
+             ra->S, ra->R, ra->d, a->S, a->R, a->d);
+  IC_REQUIRE(ra->M == a->M && g->mask == a->mask, "ic_loop_step_fwd: the region phase must read the M and mask this call's router and gate write");
+  int rc = ic_front_launch(g, ra, stream, false);
+  return rc ? rc : region_phase_launch(a, ra, stream);
 }
 
 extern "C" int ic_kwta_fwd(const float* x, float* y, float* gate, int32_t rows, int32_t d, int32_t k,

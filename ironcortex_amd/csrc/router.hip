@@ -7,21 +7,11 @@
 // keys, queries) then a wave-per-destination softmax combine.
 #include "ic_common.h"
 #include "ic_gate.h"
+#include "ic_route.h"
 
 namespace {
 
 constexpr int kRowsPerBlock = 8;
-
-// Row r of stream s of the input states / previous mask; streams may be strided (the branches of
-// one outer iteration read their inputs from arbitrary step slots).
-__device__ __forceinline__ const float* h_row(const ic_router_args& a, int s, int r) {
-  const int64_t hs = a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d;
-  return a.H + (int64_t)s * hs + (size_t)r * a.d;
-}
-__device__ __forceinline__ bool prev_on(const ic_router_args& a, int s, int r) {
-  const int64_t ms = a.mask_sstride ? a.mask_sstride : (int64_t)a.R;
-  return a.mask_prev[(int64_t)s * ms + r] != 0;
-}
 
 // ---------------------------------------------------------------- default forward
 // Workgroup = (8-row slice, destination r); incoming edges are walked in index order (the
@@ -240,85 +230,15 @@ __global__ __launch_bounds__(256) void k_router_combine_serial(ic_router_args a)
   store_row(acc, a.M + (size_t)row * d, d, lane);
 }
 
-// d <= 256: message, key and precision rows of every active incoming edge are requested together.
+// d <= 256: wave per (stream, destination); the body lives in ic_route.h (shared with the routed
+// region kernel of ic_loop_step_fwd).
 template <int DCH>
 __global__ __launch_bounds__(256) void k_router_combine(ic_router_args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.S * a.R) return;
-  const int d = a.d, s = row / a.R, r = row % a.R;
-  const int e0 = a.dst_off[r], deg = a.dst_off[r + 1] - e0;  // <= 8, checked on the host
-  const float sqrt_d = sqrtf((float)d);
-  bool act[8];
-  bool any = false;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    act[i] = i < deg && prev_on(a, s, a.src[e0 + (i < deg ? i : 0)]);
-    any |= act[i];
-  }
   RowFrag<DCH> acc;
-  zero_frag(acc);
-  if (any) {
-    RowFrag<DCH> hd, q, m[8], k[8], P[8];
-    load_row(hd, h_row(a, s, r), d, lane);
-    load_row(q, a.q + (size_t)row * d, d, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (act[i]) {
-        const size_t eo = ((size_t)s * a.E + e0 + i) * d;
-        load_row(m[i], a.msg + eo, d, lane);
-        load_row(k[i], a.keyv + eo, d, lane);
-        load_row(P[i], a.raw_P + (size_t)a.widx[e0 + i] * d, d, lane);
-      }
-    }
-    float logw[8];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      logw[i] = -INFINITY;
-      if (act[i]) {
-        const float score = wave_sum(dot_frag(q, k[i])) / sqrt_d;  // gate.py:308
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < DCH; ++j) {
-          const int c = 4 * lane + 256 * j;
-          if (c < d) {
-            float t;
-            t = m[i].v[j].x - hd.v[j].x; part += (t * t) * ic_softplus(P[i].v[j].x);
-            t = m[i].v[j].y - hd.v[j].y; part += (t * t) * ic_softplus(P[i].v[j].y);
-            t = m[i].v[j].z - hd.v[j].z; part += (t * t) * ic_softplus(P[i].v[j].z);
-            t = m[i].v[j].w - hd.v[j].w; part += (t * t) * ic_softplus(P[i].v[j].w);
-          }
-        }
-        const float mah = fminf(wave_sum(part), IC_MAX_EXP / 0.5f);  // gate.py:310
-        logw[i] = score - 0.5f * mah;
-        mx = fmaxf(mx, logw[i]);
-      }
-    }
-    float esum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (act[i]) esum += expf(logw[i] - mx);
-    const float logZ = mx + logf(fmaxf(esum, IC_EPS_DIV));  // gate.py:316
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i < deg) {
-        float w = 0.f;
-        if (act[i]) {
-          w = expf(logw[i] - logZ);
-#pragma unroll
-          for (int j = 0; j < DCH; ++j) {
-            acc.v[j].x += w * m[i].v[j].x; acc.v[j].y += w * m[i].v[j].y;
-            acc.v[j].z += w * m[i].v[j].z; acc.v[j].w += w * m[i].v[j].w;
-          }
-        }
-        if (lane == 0) a.wgt[(size_t)s * a.E + e0 + i] = w;
-      }
-    }
-  } else if (lane == 0) {
-    for (int i = 0; i < deg; ++i) a.wgt[(size_t)s * a.E + e0 + i] = 0.f;
-  }
-  store_row(acc, a.M + (size_t)row * d, d, lane);
+  combine_row<DCH>(a, row / a.R, row % a.R, lane, true, acc);
 }
 
 // ---------------------------------------------------------------- backward: stream addressing
@@ -837,9 +757,12 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
   return IC_OK;
 }
 
-extern "C" int ic_front_fwd(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream) {
+// combine = false (ic_loop_step_fwd, precision mode): the per-destination combine is left to the
+// routed region kernel that follows on the same stream.
+int ic_front_launch(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream, bool combine) {
   IC_REQUIRE(g != nullptr && a != nullptr, "ic_front_fwd: NULL args");
-  if (g->R > 64 || a->E == 0) {  // big maps: the gate's scores want the whole chip (ic_gate_fwd)
+  if (g->R > 64 || a->E == 0) {
+    IC_REQUIRE(combine, "ic_front_fwd: no fused launch for R=%d, E=%d", g->R, a->E);  // big maps: the gate's scores want the whole chip (ic_gate_fwd)
     int rc = ic_gate_fwd(g, stream);
     return rc ? rc : ic_router_fwd(a, stream);
   }
@@ -857,7 +780,8 @@ extern "C" int ic_front_fwd(const ic_gate_args* g, const ic_router_args* a, ic_s
       IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_front<DCH, true>), dim3(nsl, g->S + a->E + a->R), dim3(256), 0, st, *a, *g));
     });
     const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
-    if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
+    if (!combine) {
+    } else if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
     else if (a->d <= 512) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<2>, gcomb, dim3(256), 0, st, *a));
     else IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<4>, gcomb, dim3(256), 0, st, *a));
   } else {
@@ -865,6 +789,10 @@ extern "C" int ic_front_fwd(const ic_gate_args* g, const ic_router_args* a, ic_s
   }
   IC_LAUNCH_CHECK("ic_front_fwd");
   return IC_OK;
+}
+
+extern "C" int ic_front_fwd(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream) {
+  return ic_front_launch(g, a, stream, true);
 }
 
 extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {

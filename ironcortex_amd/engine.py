@@ -25,6 +25,7 @@ gradients (per-step rows are summed per loop instead of accumulated step by step
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -35,6 +36,10 @@ from .utils import schedule_burst, should_halt
 
 _F32, _I32, _U8 = torch.float32, torch.int32, torch.uint8
 
+
+# IC_FUSE_STEP=0: gate+router and the region phase as two C calls (ic_front_fwd, ic_region_phase_fwd)
+# instead of ic_loop_step_fwd; same results, for A/B timing
+FUSE_STEP = os.environ.get("IC_FUSE_STEP", "1") != "0"
 
 class StructImage:
     """Per-step images of a C argument struct.  Most pointer fields of a step's arguments are
@@ -326,10 +331,15 @@ class LoopEngine:
                 return H0p + b * R * d * 4, mask0p + b * R
             return CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
 
-        def front(pars: List[int], step_k: int, u_mean: float, burst: int, stream) -> List[int]:
+        pending = [False]  # front() filled ga / ra and left the launch to region() (ic_loop_step_fwd)
+        step_fwd = L.ic_loop_step_fwd
+
+        def front(pars: List[int], step_k: int, u_mean: float, burst: int, stream, defer: bool = False) -> List[int]:
             """Gate + router of len(pars) new inner steps (consecutive slots) whose H inputs are the
             outputs of steps pars[b] (-1: the loop's H_prev), as ONE launch sequence with one
-            stream per step.  Returns the step ids; region(id) must follow in order."""
+            stream per step.  Returns the step ids; region(id) must follow in order.  defer: the
+            launch is left to the region() call that follows (one C call for the whole inner step,
+            the router's combine inside the region kernel)."""
             nb = len(pars)
             i = len(parent)
             a = i0 + i
@@ -357,9 +367,12 @@ class LoopEngine:
                 ra.H_sstride, ra.mask_sstride = hs, ms
                 for k in rsaved:
                     setattr(ra, k, CP[k] + a * CS[k])
-                rc = f_fwd(ga_ref, ra_ref, stream)
-                if rc:
-                    check(rc, "ic_front_fwd")
+                if defer and nb > 1:
+                    pending[0] = True
+                else:
+                    rc = f_fwd(ga_ref, ra_ref, stream)
+                    if rc:
+                        check(rc, "ic_front_fwd")
             else:
                 rc = g_fwd(ga_ref, stream)
                 if rc:
@@ -389,7 +402,13 @@ class LoopEngine:
                 state[k] = p + (n - 1) * CS[ko]
             for k in saved:
                 setattr(fa, k, CP[k] + a * CS[k])
-            rc = p_fwd(fa_ref, stream)
+            if pending[0]:
+                pending[0] = False
+                if ga.S != n:
+                    raise RuntimeError("LoopEngine: deferred front launch and region phase disagree")
+                rc = step_fwd(ga_ref, ra_ref, fa_ref, stream)
+            else:
+                rc = p_fwd(fa_ref, stream)
             if rc:
                 check(rc, "ic_region_phase_fwd")
 
@@ -724,8 +743,8 @@ class LoopEngine:
             burst = schedule_burst(u_mean, v_hat, m.R)
             pars = [branches[b][1] for b in range(B_br)]   # IndexError for B_br > 2, as in the reference
             sls = [branches[b][0] for b in range(B_br)]
-            ids = front(pars, k, u_mean, burst, st)          # gate + router of every branch
-            region(ids[0], st, len(ids))                     # the branches share the state chain
+            ids = front(pars, k, u_mean, burst, st, FUSE_STEP)  # gate + router of every branch ...
+            region(ids[0], st, len(ids))                     # ... launched here: the branches share the state chain
             # will there be a next iteration?  (should_halt only looks at this iteration's u_mean)
             planned = k + 1 < K_inner and not should_halt(None, u_mean, k, K_inner) and len(ids) <= 8
             ha.ws_mean = P["ws_prev"] if planned else None

@@ -106,6 +106,7 @@ def lib():
         _lib.ic_gemv_chain.argtypes = [vp, ctypes.c_int32, vp]
         _lib.ic_gemv_multi.argtypes = [vp, ctypes.c_int32, vp, vp, vp]
         _lib.ic_front_fwd.argtypes = [vp, vp, vp]
+        _lib.ic_loop_step_fwd.argtypes = [vp, vp, vp, vp]
         _lib.ic_heads_gemv_fwd.argtypes = [vp, vp, vp, vp]
         _lib.ic_verify_score.argtypes = [vp, ctypes.c_int32, vp, vp, vp]
     return _lib

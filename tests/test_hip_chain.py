@@ -94,3 +94,85 @@ def test_chain_equals_sequential_calls(R, d, S, noise_vec, rows):
         if on:
             assert torch.equal(ch["last_dir"][0, r], seq[on[-1]]["last_dir"][0, r])
             assert torch.equal(ch["last_norm"][0, r], seq[on[-1]]["last_norm"][0, r])
+
+
+@pytest.mark.parametrize("S,k_total,d", [(2, 5, 32), (3, 3, 32), (6, 7, 32), (2, 4, 256), (3, 5, 256), (16, 3, 256)])
+def test_loop_step_equals_front_then_region(S, k_total, d):
+    """ic_loop_step_fwd (router combine inside the region's r/k/v kernel) == ic_front_fwd followed
+    by ic_region_phase_fwd, bit for bit, including M and the edge weights of sat-out rows."""
+    import ironcortex_amd as ic
+    from ironcortex_amd import hip
+    from ironcortex_amd.hip import ops, ENUMS
+    from tests.model_cases import load_case, MODEL_CASES
+    if d == 32:
+        _, cfg, sd, _, _ = load_case("allflags")
+    else:
+        cfg, sd = ic.CortexConfig(**dict(MODEL_CASES["allflags"], d=d, R=7)), None
+    torch.manual_seed(5)
+    prod = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
+    if sd is not None:
+        prod.load_state_dict(sd)
+    prod = prod.to(DEV)
+    R = cfg.R
+    assert cfg.d == d
+    dev = torch.device(DEV)
+    L, st = hip.lib(), hip.stream_handle()
+    g = torch.Generator().manual_seed(40 + S)
+    Hin = (torch.randn(S, R, d, generator=g) * (torch.rand(S, R, d, generator=g) < 0.3)).to(DEV)
+    mprev = (torch.rand(S, R, generator=g) < 0.6).to(torch.uint8)
+    mprev[:, 0] = 1
+    mprev[S - 1] = 0  # a stream whose senders were all off
+    mprev = mprev.to(DEV)
+    gate, router, bank = prod.gate, prod.router, prod.bank
+    assert router.enable_precision_routed_messages
+    off, nbr = gate._tables(dev)
+    tables = router._edge_tables(prod.reg_coords)
+    ebias = router._edge_bias(prod.reg_coords).detach().contiguous()
+    E = router.E
+    bank.reset_state(dev, 1)
+    kw_k, kw_soft, kw_temp = bank.kwta_now()
+    flags = bank._flags(kw_soft, bank.cells[0].disable_kwta, True) | ENUMS["IC_F_CHAIN"]
+    P = dict(bank.params())
+    P["norm_in_w"] = prod.norm_in.weight
+    sensor = torch.randn(1, d, generator=g).to(DEV)
+    state = {"num": torch.randn(1, R, d, generator=g) * 0.5, "den": torch.rand(1, R, d, generator=g) + 0.5,
+             "var": torch.rand(1, R, d, generator=g) * 0.45 + 0.05, "pred": torch.randn(1, R, d, generator=g) * 0.1,
+             "radius": torch.rand(1, R, generator=g) + 0.5, "radius_var": torch.rand(1, R, generator=g) * 0.5 + 0.1,
+             "surprise": torch.rand(1, R, generator=g), "dt": (torch.rand(1, R, generator=g) * 4).to(torch.int32)}
+    state = {k: v.to(DEV).contiguous() for k, v in state.items()}
+
+    def run(fused: bool):
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=DEV, dtype=dt)
+        out = dict(scores=z(S, R), mask=z(S, R, dt=torch.uint8), M=z(S, R, d), msg=z(S, E, d), keyv=z(S, E, d),
+                   q=z(S, R, d), wgt=z(S, E))
+        fo = torch.ones(S, dtype=torch.uint8, device=DEV)
+        ga = hip.new("ic_gate_args", S=S, R=R, d=d, sensor_idx=0, motor_idx=R - 1, k_total=k_total, force_io=1, w1=1.0,
+                     w2=0.3, w3=0.5, w4=0.2, t5=0.1, t6=0.05, gain_ema=gate.gain_ema, homeo=gate.homeo, focus_any=fo,
+                     nbr_off=off, nbr=nbr, scores=out["scores"], mask=out["mask"], H=Hin)
+        ra = ops._router_args(ops.RouterSpec(R, d, E, router.nW, True), tables, router._params(), S)
+        ra.ebias, ra.H, ra.mask_prev = ebias.data_ptr(), Hin.data_ptr(), mprev.data_ptr()
+        for k in ("M", "msg", "keyv", "q", "wgt"):
+            hip.set_field(ra, k, out[k])
+        a = ops._region_args(bank.spec, P, S, 0.4285714, kw_k, flags, kw_temp)
+        reg = {k: z(S, R, d) for k in ("H", "num_o", "den_o", "var_o", "pred_o", "x", "u1", "r_s", "k_s", "v_s", "y",
+                                       "hpre", "gate", "sterm")}
+        reg.update({k: z(S, R) for k in ("radius_o", "radius_var_o", "surprise_o", "ynorm")})
+        reg["inv_s"], reg["dt_o"] = z(S, R, 2), z(S, R, dt=torch.int32)
+        reg["last_dir"], reg["last_norm"] = z(1, R, d), z(1, R)
+        for k, t in dict(sensor=sensor, **state, **reg).items():
+            setattr(a, k, t.data_ptr())
+        a.M, a.mask = out["M"].data_ptr(), out["mask"].data_ptr()
+        if fused:
+            hip.check(L.ic_loop_step_fwd(ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(a), st), "ic_loop_step_fwd")
+        else:
+            hip.check(L.ic_front_fwd(ctypes.byref(ga), ctypes.byref(ra), st), "ic_front_fwd")
+            hip.check(L.ic_region_phase_fwd(ctypes.byref(a), st), "ic_region_phase_fwd")
+        torch.cuda.synchronize()
+        out.update(reg)
+        return out
+
+    two, one = run(False), run(True)
+    act = two["mask"].bool()
+    assert 0 < int(act.sum()) < S * R, "want active and sat-out rows"
+    for k in two:
+        assert torch.equal(one[k], two[k]), f"{k}: ic_loop_step_fwd differs from ic_front_fwd + ic_region_phase_fwd"
