@@ -331,6 +331,43 @@ class LoopEngine:
                 return H0p + b * R * d * 4, mask0p + b * R
             return CP["H"] + (i0 + par) * CS["H"], CP["mask"] + (i0 + par) * CS["mask"]
 
+        # What the next front() + region() calls need that depends only on the slot numbers can be
+        # set while the GPU is still busy with the current outer iteration (prepare_step), so that
+        # after the iteration's host sync only the chosen parents and the gate's scalars remain.
+        prepared = [-1]
+
+        def slots_front(i: int, nb: int) -> None:
+            a = i0 + i
+            ga.S = nb
+            ga.scores, ga.mask = CP["scores"] + a * CS["scores"], CP["mask"] + a * CS["mask"]
+            if E > 0:
+                ra.S, ra.M = nb, CP["M"] + a * CS["M"]
+                for k in rsaved:
+                    setattr(ra, k, CP[k] + a * CS[k])
+
+        def slots_region(i: int, n: int, step_pos: float) -> None:
+            a = i0 + i
+            fa.S, fa.flags = n, (flags | chain_flag if n > 1 else flags)
+            fa.step_pos, fa.M, fa.mask = step_pos, CP["M"] + a * CS["M"], CP["mask"] + a * CS["mask"]
+            fa.num, fa.den, fa.dt = state["num"], state["den"], state["dt"]
+            fa.var, fa.surprise = state["var"], state["surprise"]
+            fa.pred, fa.radius, fa.radius_var = state["pred"], state["radius"], state["radius_var"]
+            fa.H = CP["H"] + a * CS["H"]
+            for k, ko in out_names:
+                p = CP[ko] + a * CS[ko]
+                setattr(fa, ko, p)
+                state[k] = p + (n - 1) * CS[ko]
+            for k in saved:
+                setattr(fa, k, CP[k] + a * CS[k])
+
+        def prepare_step(nb: int, step_k: int) -> None:
+            """Slot-dependent arguments of the front() / region() pair that comes next (only call when
+            that pair is certain to run: the region state pointers advance here)."""
+            i = len(parent)
+            slots_front(i, nb)
+            slots_region(i, nb, float(step_k) / denom)
+            prepared[0] = (i, nb)
+
         pending = [False]  # front() filled ga / ra and left the launch to region() (ic_loop_step_fwd)
         step_fwd = L.ic_loop_step_fwd
 
@@ -342,7 +379,6 @@ class LoopEngine:
             the router's combine inside the region kernel)."""
             nb = len(pars)
             i = len(parent)
-            a = i0 + i
             h_in, mk_in = in_ptrs(pars[0], 0)
             hs = ms = 0
             if nb > 1:
@@ -351,22 +387,23 @@ class LoopEngine:
                 for b in range(2, nb):  # equally spaced inputs only (always true for two branches)
                     hb, mb = in_ptrs(pars[b], b)
                     if (hb - h_in) // 4 != b * hs or mb - mk_in != b * ms:
+                        prepared[0] = -1
                         return [j for b2 in range(nb) for j in front([pars[b2]], step_k, u_mean, burst, stream)]
                 if hs == R * d:
                     hs = 0
                 if ms == R:
                     ms = 0
                 if (hs == 0 and h1 - h_in != R * d * 4) or (ms == 0 and m1 - mk_in != R):
+                    prepared[0] = -1
                     return [j for b2 in range(nb) for j in front([pars[b2]], step_k, u_mean, burst, stream)]
-            ga.S, ga.H, ga.H_sstride = nb, h_in, hs
+            if prepared[0] != (i, nb):
+                slots_front(i, nb)
+            ga.H, ga.H_sstride = h_in, hs
             ga.t5, ga.t6 = w5 * float(gate.value_bias), w6 * float(u_mean)
             ga.k_total = max(0, cfg.k_active + burst)
-            ga.scores, ga.mask = CP["scores"] + a * CS["scores"], CP["mask"] + a * CS["mask"]
             if E > 0:  # gate and router read the same inputs: one launch sequence
-                ra.S, ra.H, ra.mask_prev, ra.M = nb, h_in, mk_in, CP["M"] + a * CS["M"]
+                ra.H, ra.mask_prev = h_in, mk_in
                 ra.H_sstride, ra.mask_sstride = hs, ms
-                for k in rsaved:
-                    setattr(ra, k, CP[k] + a * CS[k])
                 if defer and nb > 1:
                     pending[0] = True
                 else:
@@ -389,19 +426,10 @@ class LoopEngine:
         def region(i: int, stream, n: int = 1) -> None:
             """Region phase of the n consecutive steps i..i+n-1 (state chained from the previously
             executed step; n > 1: IC_F_CHAIN, the steps are the streams of one launch sequence)."""
-            a = i0 + i
-            fa.S, fa.flags = n, (flags | chain_flag if n > 1 else flags)
-            fa.step_pos, fa.M, fa.mask = step_pos_l[i], CP["M"] + a * CS["M"], CP["mask"] + a * CS["mask"]
-            fa.num, fa.den, fa.dt = state["num"], state["den"], state["dt"]
-            fa.var, fa.surprise = state["var"], state["surprise"]
-            fa.pred, fa.radius, fa.radius_var = state["pred"], state["radius"], state["radius_var"]
-            fa.H = CP["H"] + a * CS["H"]
-            for k, ko in out_names:
-                p = CP[ko] + a * CS[ko]
-                setattr(fa, ko, p)
-                state[k] = p + (n - 1) * CS[ko]
-            for k in saved:
-                setattr(fa, k, CP[k] + a * CS[k])
+            if prepared[0] == (i, n):
+                prepared[0] = -1  # (used up)
+            else:
+                slots_region(i, n, step_pos_l[i])
             if pending[0]:
                 pending[0] = False
                 if ga.S != n:
@@ -421,7 +449,7 @@ class LoopEngine:
         H_of = lambda i: Hf[i0 + i] if i >= 0 else H0[0]
         mask_of = lambda i: Mf[i0 + i] if i >= 0 else mask0[0]
         with torch.no_grad():
-            best, last_step, traces = self._drive((step, front, region), in_ptrs, H_of, K_inner, dev, chunk, i0,
+            best, last_step, traces = self._drive((step, front, region, prepare_step), in_ptrs, H_of, K_inner, dev, chunk, i0,
                                                   trace_views=bool(m._logits_detached and grad),
                                                   zero_in=H_prev is getattr(m, "_zero_H", None))
         n = len(parent)
@@ -597,7 +625,7 @@ class LoopEngine:
         Within an outer iteration the branches are chained only through the region state: their
         gate, router, heads and verifier run as one launch sequence with one stream per branch;
         only the region phases run branch after branch."""
-        step, front, region = steps
+        step, front, region, prepare_step = steps
         m = self.model
         cfg, gate = m.cfg, m.gate
         L, st = lib(), stream_handle()
@@ -737,7 +765,7 @@ class LoopEngine:
                 if planned:
                     v_hat = vals[40 + top[0]]  # the winner's, from the chain run for every candidate
                 branches = [branches[i] for i in top]
-                traces.append(keep(H_of(branches[0][1])))
+                trace_of = branches[0][1]
                 u_mean = vals[8 + 4 * (B_br - 1)]
             gate.value_bias = v_hat
             burst = schedule_burst(u_mean, v_hat, m.R)
@@ -745,6 +773,8 @@ class LoopEngine:
             sls = [branches[b][0] for b in range(B_br)]
             ids = front(pars, k, u_mean, burst, st, FUSE_STEP)  # gate + router of every branch ...
             region(ids[0], st, len(ids))                     # ... launched here: the branches share the state chain
+            if k > 0:  # (host work that can wait goes after the launch)
+                traces.append(keep(H_of(trace_of)))
             # will there be a next iteration?  (should_halt only looks at this iteration's u_mean)
             planned = k + 1 < K_inner and not should_halt(None, u_mean, k, K_inner) and len(ids) <= 8
             ha.ws_mean = P["ws_prev"] if planned else None
@@ -755,6 +785,8 @@ class LoopEngine:
             last = ids[-1]
             if should_halt(None, u_mean, k, K_inner):
                 break
+            if k + 1 < K_inner:
+                prepare_step(B_br, k + 1)  # while the GPU works through this iteration's launches
         sync()
         vals = ls.tolist()
         top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
