@@ -265,7 +265,10 @@ class LoopEngine:
         if fab is None or fab.device != dev or fab.numel() != nbr_:
             fab = self._fa_buf = torch.ones(nbr_, dtype=_U8, device=dev)
         focus_any = fab  # stream-ordered reuse: earlier loops' launches have read it by the time it changes
-        if focus_map.numel() > 0:
+        fo = getattr(m, "_focus_any_override", None)
+        if fo is not None and fo.shape[0] == nbr_:
+            focus_any = fo  # reasoning_loop_batch: any() of every sample's focus map in one op, a row per loop
+        elif focus_map.numel() > 0:
             focus_any.copy_(focus_map.any())
         else:
             focus_any.fill_(1)
@@ -307,7 +310,7 @@ class LoopEngine:
         # state pointers before the first step: the bank's own tensors (kept alive in `init`)
         init = dict(num=bank.num, den=bank.den, var=bank.var, pred=bank.pred, radius=bank.radius,
                     radius_var=bank.radius_var, surprise=bank.surprise, dt=bank.dt)
-        init = {k: v.detach().contiguous() for k, v in init.items()}
+        init = {k: (v if not v.requires_grad and v.is_contiguous() else v.detach().contiguous()) for k, v in init.items()}
         state = {k: v.data_ptr() for k, v in init.items()}
         out_names = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o")]
         if afd:
@@ -638,7 +641,10 @@ class LoopEngine:
         CP, CS = chunk.ptr, chunk.stride
         afd = "surprise_o" in CP
         aux_on = ver is not None and m.verify.aux_dim > 0
-        if aux_on:  # model.py:396-404: [mixer energy, mean surprise (written per step), attention entropy]
+        aux_row = getattr(m, "_aux_override", None)
+        if aux_on and aux_row is not None:  # reasoning_loop_batch: the rows of all samples built in one go
+            hs["buf"]["aux"].copy_(aux_row)
+        elif aux_on:  # model.py:396-404: [mixer energy, mean surprise (written per step), attention entropy]
             ent = getattr(m.local_mix.attn, "last_attn_entropy", None)
             a02 = torch.stack([m.local_mix.last_energy.detach().reshape(()),
                                (ent.detach().reshape(()).to(dev) if ent is not None else torch.zeros((), device=dev))])

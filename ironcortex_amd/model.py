@@ -90,6 +90,7 @@ class CortexReasoner(nn.Module):
         self._profile_mem = {"attention": 0, "routing": 0, "region": 0}
         self._sensor_cache = None
         self._sensor_override = None
+        self._focus_any_override = self._aux_override = None
         self.counters = {"inner_steps": 0}
         self._units = None  # device counters for bench.py (off by default)
         self._loop_cache = None
@@ -123,7 +124,7 @@ class CortexReasoner(nn.Module):
                 "bwd_region_launches": u[5], "bwd_pairs": u[6], "bwd_unique_regions": u[7]}
 
     def detach_state(self) -> None:
-        if hasattr(self, "work"):
+        if hasattr(self, "work") and self.work.slots.requires_grad:
             self.work.slots = self.work.slots.detach()
         self.bank.detach_state()
 
@@ -396,9 +397,25 @@ class CortexReasoner(nn.Module):
             if one_node:
                 eng.begin_batch(N, K_inner * (1 if self.cfg.train_deterministic_inner_loop else max(1, self.cfg.B_br)), dev)
             recorded = []
+            fo_all = aux_all = None
+            if batched is not None and eng.usable(H_zero, not self._logits_detached):
+                # per-loop inputs of the engine that do not depend on the loops' results: one batch
+                # of ops for all N loops instead of a handful per loop (the GPU idles between loops)
+                nb_ = 1 if self.cfg.train_deterministic_inner_loop else max(1, self.cfg.B_br)
+                if focus_batch.numel() > 0:
+                    fo_all = focus_batch.reshape(N, -1).any(1, keepdim=True).to(torch.uint8).repeat(1, nb_)
+                else:
+                    fo_all = torch.ones(N, nb_, dtype=torch.uint8, device=dev)
+                if self.verify is not None and getattr(self.verify, "aux_dim", 0) > 0:
+                    aux_all = torch.zeros(N, nb_, 4, device=dev)
+                    aux_all[:, :, 0] = batched[1].detach().reshape(N, 1)
+                    if batched[2] is not None:
+                        aux_all[:, :, 2] = batched[2].detach().reshape(N, 1).to(dev)
             for b in range(N):
                 self.detach_state()
                 H_prev, mask_prev = H_zero, mask_zero
+                self._focus_any_override = fo_all[b] if fo_all is not None else None
+                self._aux_override = aux_all[b] if aux_all is not None else None
                 if batched is not None:  # what a per-sequence mixer call would have left behind
                     self._sensor_override = batched[0][b]
                     self.local_mix.last_energy = batched[1][b]
@@ -421,6 +438,7 @@ class CortexReasoner(nn.Module):
                         H_l[b] = H_eng[j]
         finally:
             self._sensor_override = None
+            self._focus_any_override = self._aux_override = None
             self._zero_H = None
             eng._batch = None
         H_all = H_l if torch.is_tensor(H_l) else torch.stack(H_l)

@@ -103,7 +103,9 @@ class RegionBank:
     def detach_state(self) -> None:
         """region.py:148-157 for every cell."""
         for k in ("num", "den", "var", "pred", "radius", "radius_var", "surprise"):
-            setattr(self, k, getattr(self, k).detach())
+            t = getattr(self, k)
+            if t.requires_grad:  # (views of the loop engine's arena never do)
+                setattr(self, k, t.detach())
 
     # ------------------------------------------------------------------ parameters
     def params(self, lo: int = 0, hi: Optional[int] = None) -> Dict[str, torch.Tensor]:
