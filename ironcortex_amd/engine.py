@@ -476,22 +476,24 @@ class LoopEngine:
                     f[ko][lj].copy_(f[ko][li])
             li = lj
         if n > 0:
-            bank.num, bank.den, bank.dt = f["num_o"][li:li + 1], f["den_o"][li:li + 1], f["dt_o"][li:li + 1]
+            nar = torch.narrow  # (cheaper than slicing: this runs once per loop while the GPU idles)
+            bank.num, bank.den, bank.dt = nar(f["num_o"], 0, li, 1), nar(f["den_o"], 0, li, 1), nar(f["dt_o"], 0, li, 1)
             if afd:
-                bank.var, bank.surprise = f["var_o"][li:li + 1], f["surprise_o"][li:li + 1]
+                bank.var, bank.surprise = nar(f["var_o"], 0, li, 1), nar(f["surprise_o"], 0, li, 1)
             if use_pred:
-                bank.pred = f["pred_o"][li:li + 1]
+                bank.pred = nar(f["pred_o"], 0, li, 1)
             if rt_:
-                bank.radius, bank.radius_var = f["radius_o"][li:li + 1], f["radius_var_o"][li:li + 1]
+                bank.radius, bank.radius_var = nar(f["radius_o"], 0, li, 1), nar(f["radius_var_o"], 0, li, 1)
             if prec:
-                router._last_wgt = f["wgt"][wgt_li:wgt_li + 1, :E]
+                router._last_wgt = nar(nar(f["wgt"], 0, wgt_li, 1), 1, 0, E)
             self._state_in_arena = True
         if m._units is not None and E > 0 and n > 0:  # bench.py's device-side unit counters
             self._unit_log.append((chunk, i0, list(parent), mask0[0]))
             if not grad:
                 self.flush_units()
 
-        reg_mask = mask_of(best).bool()
+        # (reasoning_loop_batch converts the stacked masks of its loops in one op)
+        reg_mask = mask_of(best) if (self._batch is not None and grad and n > 0) else mask_of(best).bool()
         if grad and n > 0:
             s = _Sample()
             s.chunk, s.i0, s.n, s.parent, s.best, s.step_pos = chunk, i0, n, parent, best, step_pos_l
@@ -651,7 +653,12 @@ class LoopEngine:
             hs["buf"]["aux"][:, 0::2] = a02
         ha.aux_surprise = P["aux"] + 4 if aux_on else None
         n_slots = m.work.slots.shape[0]
-        slots0 = m.work.slots.detach().reshape(1, n_slots, d).repeat(nb, 1, 1)
+        # the workspace the loop starts from, once per branch (stream-ordered reuse of one buffer:
+        # the previous loop's first heads launch read it long before this copy runs)
+        slots0 = hs["buf"].get("slots0")
+        if slots0 is None or slots0.shape != (nb, n_slots, d):
+            slots0 = hs["buf"]["slots0"] = torch.empty(nb, n_slots, d, device=dev)
+        slots0.copy_(m.work.slots.detach())
         s0p = slots0.data_ptr()
         slots_ptr = lambda i, b: CP["slots"] + (i0 + i) * CS["slots"] if i >= 0 else s0p + b * n_slots * d * 4
         lsp = P["ls"]

@@ -16,13 +16,14 @@ from .constants import EPS_DIV, EPS_LOG
 from .flat import ArenaParameter, FlatParams
 from .hip import ops
 from .region import _Lin
-from .utils import neighbor_csr
+from .utils import FastAttrs, neighbor_csr
 
 _HEX_DIRS = ((1, 0), (1, -1), (0, -1), (-1, 0), (-1, 1), (0, 1))
 
 
-class Gate(nn.Module):
+class Gate(FastAttrs, nn.Module):
     """Discrete compute allocator over regions (gate.py:16-96)."""
+    _plain_attrs = frozenset({"value_bias"})
 
     def __init__(self, R: int, neighbor_indices: List[List[int]], io_idxs: Dict[str, int]):
         super().__init__()
@@ -89,8 +90,9 @@ class Gate(nn.Module):
         self.homeo += eta * (reg_mask.float() - target)
 
 
-class Router(nn.Module):
+class Router(FastAttrs, nn.Module):
     """Hex-graph message router with learned edge transforms and a Fourier relative bias."""
+    _plain_attrs = frozenset({"_bias_cache", "_last_wgt", "hold_bias", "_tables", "_tables_key", "_geom"})
 
     def __init__(self, neighbor_indices: List[List[int]], d: int, R: int, *,
                  enable_precision_routed_messages: bool = False, vectorized: bool = True,

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .utils import KWTA, RMSNorm
+from .utils import KWTA, FastAttrs, RMSNorm
 
 
 class VecLinear(nn.Linear):
@@ -19,8 +19,9 @@ class VecLinear(nn.Linear):
         return F.linear(x, self.weight, self.bias)
 
 
-class Workspace(nn.Module):
+class Workspace(FastAttrs, nn.Module):
     """N slots of width d shared by all regions; writes are additive then KWTA'd (k = d//4)."""
+    _fast_buffers = frozenset({"slots"})
 
     def __init__(self, d: int, N_slots: int = 8):
         super().__init__()

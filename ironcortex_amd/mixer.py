@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .constants import EPS_DIV, EPS_LOG, MAX_EXP
-from .utils import extract_spans, init_weights, masked_mean
+from .utils import FastAttrs, extract_spans, init_weights, masked_mean
 
 
 def make_freq_bank(m: int, d_coord: int, kind: str = "log", base: float = 10000.0, sigma: float = 1.0,
@@ -147,8 +147,9 @@ class IronRoPESelfAttention(nn.Module):
         return x + y
 
 
-class AdaptiveFilterAttention(nn.Module):
+class AdaptiveFilterAttention(FastAttrs, nn.Module):
     """Dot-product attention times exp(-alpha |lag| dt) (adaptive_filter_attention.py:8-127)."""
+    _plain_attrs = frozenset({"last_attn_entropy"})
 
     def __init__(self, d_model: int, n_head: int, dt: float = 1.0, alpha: float = 0.0, *,
                  debug_exact: bool = False, exact_threshold: int = 64):
@@ -200,9 +201,10 @@ class AdaptiveFilterAttention(nn.Module):
                 "attn_entropy_mean": float(self.last_attn_entropy)}
 
 
-class LocalTokenMixer(nn.Module):
+class LocalTokenMixer(FastAttrs, nn.Module):
     """Anchor tokens + one attention block; returns the mean of the focused positions
     (iron_rope.py:254-374)."""
+    _fast_buffers = frozenset({"last_energy"})
 
     def __init__(self, d: int, n_head: int = 4, block_size: int = 8192, m_tok: int = 64, use_afa: bool = False):
         super().__init__()

@@ -25,11 +25,14 @@ from .hip import ops
 from .mixer import LocalTokenMixer
 from .region import RegionBank, RWKVRegionCell
 from .sdr import SparseTokenEncoder
-from .utils import (RegionFFState, RMSNorm, context_logprob, goodness, init_weights, schedule_burst,
+from .utils import (FastAttrs, RegionFFState, RMSNorm, context_logprob, goodness, init_weights, schedule_burst,
                     should_halt, uncertainty_from_logits)
 
 
-class CortexReasoner(nn.Module):
+class CortexReasoner(FastAttrs, nn.Module):
+    _plain_attrs = frozenset({"_sensor_override", "_focus_any_override", "_aux_override", "_sensor_cache", "_loop_cache",
+                              "_in_loop", "_zero_H", "_heads_used"})
+
     def __init__(self, neighbor_indices: List[List[int]], reg_coords: torch.Tensor, io_idxs: Dict[str, int],
                  cfg: CortexConfig):
         super().__init__()
@@ -442,4 +445,5 @@ class CortexReasoner(nn.Module):
             self._zero_H = None
             eng._batch = None
         H_all = H_l if torch.is_tensor(H_l) else torch.stack(H_l)
-        return (H_all, torch.stack(M_l), torch.stack(L_l), T_l, torch.stack(E_l), torch.stack(A_l))
+        M_all = torch.stack([mk.bool() for mk in M_l]) if len({mk.dtype for mk in M_l}) > 1 else torch.stack(M_l).bool()
+        return (H_all, M_all, torch.stack(L_l), T_l, torch.stack(E_l), torch.stack(A_l))

@@ -128,3 +128,21 @@ class RegionFFState(nn.Module):
         if mean_prec is not None:
             target = target + kappa * (mean_prec.to(self.tau.dtype) - target_prec)
         self.tau = (1 - alpha) * self.tau + alpha * target
+
+
+class FastAttrs:
+    """Mix-in for nn.Module subclasses: nn.Module.__setattr__ walks the parameter / buffer / module
+    registries on every assignment (1-2 us); the host-side bookkeeping attributes named in
+    _plain_attrs (never tensors that must follow .to() or state_dict) and the already registered
+    buffers named in _fast_buffers are set directly.  A reasoning loop assigns ~30 of them, while the
+    GPU waits."""
+    _plain_attrs: frozenset = frozenset()
+    _fast_buffers: frozenset = frozenset()
+
+    def __setattr__(self, name, value):
+        if name in self._plain_attrs:
+            object.__setattr__(self, name, value)
+        elif name in self._fast_buffers and isinstance(value, torch.Tensor) and name in self.__dict__.get("_buffers", ()):
+            self._buffers[name] = value
+        else:
+            super().__setattr__(name, value)
