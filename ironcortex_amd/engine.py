@@ -40,6 +40,8 @@ _F32, _I32, _U8 = torch.float32, torch.int32, torch.uint8
 # IC_FUSE_STEP=0: gate+router and the region phase as two C calls (ic_front_fwd, ic_region_phase_fwd)
 # instead of ic_loop_step_fwd; same results, for A/B timing
 FUSE_STEP = os.environ.get("IC_FUSE_STEP", "1") != "0"
+# IC_DEFER_SYNC=0: every loop waits for its last iteration's scores before it returns (A/B timing)
+DEFER_SYNC = os.environ.get("IC_DEFER_SYNC", "1") != "0"
 
 class StructImage:
     """Per-step images of a C argument struct.  Most pointer fields of a step's arguments are
@@ -116,6 +118,16 @@ class StepArena:
         self.cur, self.pos = 0, 0
 
 
+class DeferredMask:
+    """Active-region mask of a recorded loop whose winner is read later (LoopEngine.resolve_pending):
+    .value is the uint8 [R] view once resolved."""
+
+    __slots__ = ("value",)
+
+    def __init__(self):
+        self.value = None
+
+
 class _Sample:
     """Record of one loop: what the backward needs to replay the steps in reverse."""
 
@@ -139,6 +151,11 @@ class LoopEngine:
         self._hs_ok = False
         self._fa_buf = None
         self._batch = None  # loops of one reasoning_loop_batch call, differentiated as ONE node
+        # A recorded loop of a batch does not wait for its last iteration's scores: the winner is
+        # read (resolve_pending) after the NEXT loop's first launch is queued, so the host work
+        # between two loops overlaps the GPU instead of following a stream sync.
+        self._pending = None
+        self._events = None
         self._wsb = None
         self.counters = {"batch_bwd": 0, "loop_bwd": 0}  # backward passes taken all-loops-at-once / loop by loop
         model._coord.register(self._begin_pass, self._finish_pass)
@@ -157,9 +174,24 @@ class LoopEngine:
             return True  # the first phase() call builds the state; done in run()
         return not any(getattr(b, k).requires_grad for k in ("num", "den", "var", "pred", "radius", "radius_var"))
 
+    def resolve_pending(self) -> None:
+        """Finish the bookkeeping of the last recorded loop whose final scores were not waited for:
+        wait for the event recorded after its last launch, read the scores, pick the winner."""
+        p, self._pending = self._pending, None
+        if p is None:
+            return
+        p["event"].synchronize()
+        vals = p["ls"].tolist()
+        branches = p["branches"]
+        top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(p["B_br"], 2)]
+        best = branches[top[0]][1]
+        p["traces"].append(p["H_of"](best))
+        p["finish"](best)
+
     def reset(self) -> None:
         """Start of a new forward/backward pass: every step slot may be reused.  The bank's state
         tensors are views of the last loop's final slot until now; copy them out first."""
+        self.resolve_pending()
         self._rescue_state()
         self.flush_units()
         self._sess = None
@@ -169,6 +201,7 @@ class LoopEngine:
             self._arena.reset()
 
     def _rescue_state(self) -> None:
+        self.resolve_pending()
         if not self._state_in_arena:
             return
         m = self.model
@@ -456,10 +489,11 @@ class LoopEngine:
                                                   trace_views=bool(m._logits_detached and grad),
                                                   zero_in=H_prev is getattr(m, "_zero_H", None))
         n = len(parent)
+        deferred = best is None  # the winner is not known yet (resolve_pending() fills it in)
         last_logits = (chunk.fields["logits"][i0 + last_step] if last_step >= 0 else torch.zeros(m.V, device=dev))
         if not (m._logits_detached and grad):  # train_step stacks the loops' logits before the arena is reset
             last_logits = last_logits.clone()
-        if best >= 0:
+        if not deferred and best >= 0:
             m.work.slots = chunk.fields["slots"][i0 + best]
 
         # ---- hand the state back to the bank: views of the last slot, copied out by reset()
@@ -493,7 +527,10 @@ class LoopEngine:
                 self.flush_units()
 
         # (reasoning_loop_batch converts the stacked masks of its loops in one op)
-        reg_mask = mask_of(best) if (self._batch is not None and grad and n > 0) else mask_of(best).bool()
+        if deferred:
+            reg_mask = DeferredMask()
+        else:
+            reg_mask = mask_of(best) if (self._batch is not None and grad and n > 0) else mask_of(best).bool()
         if grad and n > 0:
             s = _Sample()
             s.chunk, s.i0, s.n, s.parent, s.best, s.step_pos = chunk, i0, n, parent, best, step_pos_l
@@ -502,7 +539,18 @@ class LoopEngine:
             s.keep = (focus_any, tables, rP, bP)
             s.ebias_grad = bool(ebias.requires_grad)
             s.zero_in = H_prev is getattr(m, "_zero_H", None)
-            if self._batch is not None:  # differentiated by end_batch() together with the other loops
+            if deferred:
+                slots_f = chunk.fields["slots"]
+
+                def finish(best_: int, s=s, reg_mask=reg_mask) -> None:
+                    s.best = best_
+                    reg_mask.value = mask_of(best_)
+                    m.work.slots = slots_f[i0 + best_]
+
+                self._pending["finish"] = finish
+                self._batch["samples"].append(s)
+                H_cur = H_of(last_step)  # placeholder (end_batch() returns the real rows)
+            elif self._batch is not None:  # differentiated by end_batch() together with the other loops
                 self._batch["samples"].append(s)
                 H_cur = H_of(best)
             else:
@@ -658,8 +706,14 @@ class LoopEngine:
         slots0 = hs["buf"].get("slots0")
         if slots0 is None or slots0.shape != (nb, n_slots, d):
             slots0 = hs["buf"]["slots0"] = torch.empty(nb, n_slots, d, device=dev)
-        slots0.copy_(m.work.slots.detach())
         s0p = slots0.data_ptr()
+
+        def settle() -> None:
+            """Before this loop's first launch that writes the pinned score block (or its first
+            sync): the previous loop's winner, then the workspace this loop starts from."""
+            self.resolve_pending()
+            slots0.copy_(m.work.slots.detach())
+
         slots_ptr = lambda i, b: CP["slots"] + (i0 + i) * CS["slots"] if i >= 0 else s0p + b * n_slots * d * 4
         lsp = P["ls"]
         heads_fwd, chain, vscore, steer_sel = L.ic_heads_fwd, L.ic_gemv_chain, L.ic_verify_score, L.ic_steer_select
@@ -733,6 +787,7 @@ class LoopEngine:
             raise RuntimeError("the branching reasoning loop needs the planner, critic and energy verifier "
                                "(reference model.py:376-438)")
         if cfg.train_deterministic_inner_loop:
+            settle()
             cur, u_mean = -1, 0.0
             for k in range(K_inner):
                 gate.value_bias = 0.0
@@ -749,12 +804,16 @@ class LoopEngine:
         branches = [(-1, -1) for _ in range(B_br)]  # (step whose workspace slots, step whose H / mask)
         u_mean = 0.0
         planned = False  # True when the previous iteration already ran the planner for both candidates
+        settled = False
         for k in range(K_inner):
             if k == 0 and zero_in and self._vhat0 is not None:
                 # every loop of a train_step starts from the shared all-zero state: the planner's
                 # input (mean of the active rows: none) and so v_hat are the same as for the first loop
                 vals = None
             elif not planned:
+                if not settled:
+                    settle()
+                    settled = True
                 # planner / critic on the best candidate so far, chosen on the device (model.py:371-386)
                 sa.n_cand = len(branches)
                 for c, (_, hstep) in enumerate(branches):
@@ -788,6 +847,9 @@ class LoopEngine:
             region(ids[0], st, len(ids))                     # ... launched here: the branches share the state chain
             if k > 0:  # (host work that can wait goes after the launch)
                 traces.append(keep(H_of(trace_of)))
+            if not settled:  # the previous loop's winner is read while the GPU runs this loop's first step
+                settle()
+                settled = True
             # will there be a next iteration?  (should_halt only looks at this iteration's u_mean)
             planned = k + 1 < K_inner and not should_halt(None, u_mean, k, K_inner) and len(ids) <= 8
             ha.ws_mean = P["ws_prev"] if planned else None
@@ -800,6 +862,16 @@ class LoopEngine:
                 break
             if k + 1 < K_inner:
                 prepare_step(B_br, k + 1)  # while the GPU works through this iteration's launches
+        if DEFER_SYNC and trace_views and self._batch is not None and last >= 0:
+            # recorded loop of a batch: do not wait here (see resolve_pending)
+            evs = self._events
+            if evs is None:
+                evs = self._events = [[torch.cuda.Event(), torch.cuda.Event()], 0]
+            ev = evs[0][evs[1]]
+            evs[1] ^= 1
+            ev.record(torch.cuda.current_stream(dev))
+            self._pending = {"event": ev, "ls": ls, "branches": branches, "B_br": B_br, "traces": traces, "H_of": H_of}
+            return None, last, traces
         sync()
         vals = ls.tolist()
         top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
@@ -1038,6 +1110,7 @@ class LoopEngine:
     def end_batch(self, sensors: torch.Tensor) -> Optional[torch.Tensor]:
         """[n_recorded, R, d] final states of the recorded loops, as one autograd node whose input
         is the batch of sensor vectors (row j of `sensors` fed recorded loop j)."""
+        self.resolve_pending()
         bt, self._batch = self._batch, None
         if bt is None or not bt["samples"]:
             return None

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from .config import CortexConfig
 from .constants import EPS_DIV
 from .energy import EnergyVerifierHead
-from .engine import LoopEngine
+from .engine import DeferredMask, LoopEngine
 from .flat import FlatParams
 from .gate import Gate, Router
 from .heads import CriticHead, PlannerHead, RTDHead, TokenHead_MFS, Workspace
@@ -414,16 +414,20 @@ class CortexReasoner(FastAttrs, nn.Module):
                     aux_all[:, :, 0] = batched[1].detach().reshape(N, 1)
                     if batched[2] is not None:
                         aux_all[:, :, 2] = batched[2].detach().reshape(N, 1).to(dev)
+            # rows of the per-batch tensors: one unbind each instead of an indexing op per loop
+            rows = lambda t: t.unbind(0) if t is not None else None
+            fo_r, aux_r = rows(fo_all), rows(aux_all)
+            sv_r, en_r, ent_r = (rows(batched[0]), rows(batched[1]), rows(batched[2])) if batched is not None else (None,) * 3
             for b in range(N):
                 self.detach_state()
                 H_prev, mask_prev = H_zero, mask_zero
-                self._focus_any_override = fo_all[b] if fo_all is not None else None
-                self._aux_override = aux_all[b] if aux_all is not None else None
+                self._focus_any_override = fo_r[b] if fo_r is not None else None
+                self._aux_override = aux_r[b] if aux_r is not None else None
                 if batched is not None:  # what a per-sequence mixer call would have left behind
-                    self._sensor_override = batched[0][b]
-                    self.local_mix.last_energy = batched[1][b]
-                    if batched[2] is not None:
-                        self.local_mix.attn.last_attn_entropy = batched[2][b]
+                    self._sensor_override = sv_r[b]
+                    self.local_mix.last_energy = en_r[b]
+                    if ent_r is not None:
+                        self.local_mix.attn.last_attn_entropy = ent_r[b]
                 n_rec = len(eng._batch["samples"]) if one_node else 0
                 H_cur, reg_mask, logits, traces = self.reasoning_loop(tokens_batch[b], K_inner, focus_batch[b], mask_prev, H_prev)
                 if one_node and len(eng._batch["samples"]) > n_rec:
@@ -434,6 +438,7 @@ class CortexReasoner(FastAttrs, nn.Module):
                 A_l.append(ent.detach().to(dev))
             if one_node:
                 H_eng = eng.end_batch(batched[0][recorded] if len(recorded) != N else batched[0])
+                M_l = [mk.value if isinstance(mk, DeferredMask) else mk for mk in M_l]  # (all resolved by now)
                 if len(recorded) == N:
                     H_l = H_eng  # [N,R,d]
                 else:
@@ -444,6 +449,7 @@ class CortexReasoner(FastAttrs, nn.Module):
             self._focus_any_override = self._aux_override = None
             self._zero_H = None
             eng._batch = None
+            eng._pending = None
         H_all = H_l if torch.is_tensor(H_l) else torch.stack(H_l)
         M_all = torch.stack([mk.bool() for mk in M_l]) if len({mk.dtype for mk in M_l}) > 1 else torch.stack(M_l).bool()
         return (H_all, M_all, torch.stack(L_l), T_l, torch.stack(E_l), torch.stack(A_l))
