@@ -66,6 +66,9 @@ def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
         "region_rkv_bwd": st["u_b"] * 3 * dd + st["n_b"] * (16 + (6 if afd else 0)) * vec,
         "region_out_bwd": st["u_b"] * dd + st["n_b"] * 4 * vec,
     }
+    if st.get("routed"):  # ic_loop_step_fwd: the router's combine rides in the r/k/v kernel (per launch: e_f active
+        # incoming edges -> message, key, precision rows; q_f destinations -> state and query rows in, M row out)
+        table["region_rkv"] += (3 * st["e_f"] + 3 * st["q_f"]) * vec
     if "e" in st:  # the kernel sweep also prices the router: e = distinct active edges, q = destinations
         e, q, R, prec = st["e"], st.get("q", 0), st["R"], st.get("prec", False)
         table.update({
@@ -233,7 +236,10 @@ def main():
             lf, lb = max(1.0, units["fwd_region_launches"]), max(1.0, units["bwd_region_launches"])
             st = dict(n_f=units["region_steps"] / lf, u_f=units["fwd_unique_regions"] / lf,
                       n_b=units["bwd_pairs"] / lb, u_b=units["bwd_unique_regions"] / lb,
-                      afd=cfg.enable_adaptive_filter_dynamics)
+                      afd=cfg.enable_adaptive_filter_dynamics,
+                      routed=bool(cfg.enable_precision_routed_messages and cfg.d <= 256 and not cfg.train_deterministic_inner_loop
+                                  and cfg.B_br > 1 and os.environ.get("IC_FUSE_STEP", "1") != "0"),
+                      e_f=units["active_edges"] / lf, q_f=units["dst_regions"] / lf)
             ab = algorithmic_bytes(name, cfg.d, st)
             avg_s = ms / launches * 1e-3
             achieved = ab / avg_s / 1e9

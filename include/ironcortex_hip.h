@@ -284,7 +284,7 @@ int ic_gate_fwd(const ic_gate_args* a, ic_stream_t stream);
  * in S, R, d.  Falls back to the two calls for R > 64 or E == 0. */
 int ic_front_fwd(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream);
 
-/* One whole inner step (reference model.py:254-283, forward_inner_step: gate -> router -> region
+/* One whole inner step (reference model.py:254-290, forward_inner_step: gate -> router -> region
  * bank): ic_front_fwd(g, ra) followed by ic_region_phase_fwd(a) on the same stream, same results
  * bit for bit.  ra->M must be a->M and g->mask must be a->mask.  With precision routing, d <= 256,
  * R <= 64 and IC_F_CHAIN the router's per-destination combine has no launch of its own: the

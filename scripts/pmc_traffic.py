@@ -12,7 +12,8 @@ import sys
 
 def short(name: str) -> str:
     n = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
-    return n[2:] if n.startswith("k_") else n
+    n = n[2:] if n.startswith("k_") else n
+    return {"region_rkv_routed": "region_rkv"}.get(n, n)  # same kernel id in the library's timing table
 
 
 def avg(path: str, counter: str):
