@@ -179,3 +179,46 @@ def test_early_halt_engine_equals_general_path(monkeypatch):
         torch.testing.assert_close(g, grads[1][0][n], rtol=2e-3, atol=2e-5 * max(1.0, float(g.abs().max())), msg=n)
     for k in KEYS:
         assert grads[0][1][k] == pytest.approx(grads[1][1][k], rel=1e-3, abs=1e-4), k
+
+
+@pytest.mark.parametrize("name", ["default", "allflags"])
+def test_deferred_winner_equals_immediate(name, monkeypatch):
+    """A recorded loop of a batch reads its winner after the next loop's first launch is queued
+    (LoopEngine.resolve_pending) instead of waiting for its own last scores: same outputs, masks,
+    traces, losses and gradients, bit for bit, as with the wait (IC_DEFER_SYNC=0), and the
+    deferral is the path taken."""
+    import ironcortex_amd as ic
+    from ironcortex_amd import engine as E
+    gold, cfg, sd, tokens, focus = load_case(name)
+    res = []
+    for defer in (True, False):
+        monkeypatch.setattr(E, "DEFER_SYNC", defer)
+        model = build(cfg, sd)
+        n_resolved = [0]
+        orig = model.engine.resolve_pending
+
+        def counted(orig=orig, n=n_resolved, eng=model.engine):
+            n[0] += eng._pending is not None
+            orig()
+
+        model.engine.resolve_pending = counted
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        seed_train()
+        out = ic.train_step(model, opt, tokens.to(DEV), ic.LossWeights(), torch.device(DEV))
+        assert (n_resolved[0] > 0) == defer, n_resolved
+        assert model.engine._pending is None
+        grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+        model.zero_grad()
+        seed_train()
+        H, m, logits, traces, en, ent = model.reasoning_loop_batch(tokens.to(DEV), cfg.K_inner, focus.to(DEV))
+        res.append((out, grads, H.detach().clone(), m.clone(), logits.detach().clone(), [[t.clone() for t in tr] for tr in traces]))
+    (o0, g0, H0, m0, l0, t0), (o1, g1, H1, m1, l1, t1) = res
+    for k in KEYS:
+        assert o0[k] == o1[k], k
+    for n in g0:
+        assert (g0[n] is None) == (g1[n] is None) and (g0[n] is None or torch.equal(g0[n], g1[n])), n
+    assert torch.equal(H0, H1) and torch.equal(m0, m1) and m0.dtype == torch.bool and torch.equal(l0, l1)
+    assert [len(t) for t in t0] == [len(t) for t in t1]
+    for a, b in zip(t0, t1):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
