@@ -5,6 +5,7 @@ edge nudges -> homeostasis -> optimizer.step."""
 from __future__ import annotations
 
 import random
+import weakref
 from dataclasses import dataclass
 from typing import Dict, List
 
@@ -42,13 +43,27 @@ def make_negatives(clean_tokens: torch.Tensor, V: int):
     return (torch.stack(neg).to(dev), torch.stack(focus).to(dev), torch.stack(targets), torch.stack(masks), real)
 
 
+_MODULES = weakref.WeakKeyDictionary()  # model -> tuple of its modules (the tree is fixed after construction)
+
+
+def _ensure_training(model) -> None:
+    """model.train(), skipped when every module is already in training mode: train() walks the
+    tree and re-assigns the flag through nn.Module.__setattr__ on ~220 modules (0.3 ms per step)."""
+    mods = _MODULES.get(model)
+    if mods is None:
+        mods = _MODULES[model] = tuple(model.modules())
+    for mod in mods:
+        if not mod.training:
+            model.train()
+            return
+
+
 def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_tokens: torch.Tensor,
                λ: LossWeights, device: torch.device, dp=None) -> Dict[str, float]:
     """One FF training step.  dp (ironcortex_amd.parallel.DataParallel, optional) shards the batch
     over ranks: clean_tokens is then this rank's shard and the one exchange per step happens
     between backward and the updates."""
-    if not all(mod.training for mod in model.modules()):  # (train() re-assigns the flag on every module: 0.3 ms)
-        model.train()
+    _ensure_training(model)
     model.detach_state()
     cfg = model.cfg
     B, T = clean_tokens.shape
