@@ -78,25 +78,53 @@ __device__ __forceinline__ void prologue_row(const ic_region_args& a, int row, i
 // inactive: each is one trace EMA step on its own message row (region.py:140-146) and dt+1.
 // ROUTED (ic_loop_step_fwd): the message rows are not read from M but from the workgroup's LDS
 // copy (mrows[s][d], combined from the edges' messages at the start of the kernel).
+// The rows of the chain prologue that do not depend on the stream (the routed kernel requests them
+// before its combines, so they arrive while the combines' dependent loads are in flight).
+template <int DCH>
+struct ChainRows {
+  RowFrag<DCH> sv, win, w, p;
+  int dt;
+};
+template <int DCH>
+__device__ __forceinline__ void chain_rows(const ic_region_args& a, int r, int lane, ChainRows<DCH>& c) {
+  const int d = a.d;
+  const bool norm_in = a.flags & IC_F_NORM_IN, pred = a.flags & IC_F_PRED;
+  const bool io = norm_in && a.sensor && (r == a.sensor_idx || r == a.motor_idx);
+  zero_frag(c.p);
+  if (io) load_row(c.sv, a.sensor, d, lane);
+  if (norm_in) load_row(c.win, a.norm_in_w, d, lane);
+  load_row(c.w, a.norm_w + (size_t)r * d, d, lane);
+  if (pred) load_row(c.p, a.pred + (size_t)r * d, d, lane);
+  c.dt = a.dt[r];
+}
+
 template <int DCH, bool ROUTED>
 __device__ __forceinline__ void chain_prologue(const ic_region_args& a, int r, int s, int prev, int lane,
                                                float one_minus_alpha, RowFrag<DCH>& u1, RowFrag<DCH>& x,
                                                float& inv0, float& inv1, float& steps,
-                                               const float* mrows) {
+                                               const float* mrows, const ChainRows<DCH>& pre) {
   const int d = a.d;
   const bool norm_in = a.flags & IC_F_NORM_IN, pred = a.flags & IC_F_PRED;
   const bool io = norm_in && a.sensor && (r == a.sensor_idx || r == a.motor_idx);
   RowFrag<DCH> u, sv, win, p, w;
-  if (ROUTED) load_row(u, mrows + s * d, d, lane);
-  else load_row(u, a.M + ((size_t)s * a.R + r) * d, d, lane);
-  if (io) load_row(sv, a.sensor, d, lane);
-  if (norm_in) load_row(win, a.norm_in_w, d, lane);
-  load_row(w, a.norm_w + (size_t)r * d, d, lane);
   int dtv = 0;
   zero_frag(p);
-  if (prev < 0) {
-    if (pred) load_row(p, a.pred + (size_t)r * d, d, lane);
-    dtv = a.dt[r];
+  if (ROUTED) {
+    load_row(u, mrows + s * d, d, lane);
+    sv = pre.sv; win = pre.win; w = pre.w;
+    if (prev < 0) {
+      p = pre.p;
+      dtv = pre.dt;
+    }
+  } else {
+    load_row(u, a.M + ((size_t)s * a.R + r) * d, d, lane);
+    if (io) load_row(sv, a.sensor, d, lane);
+    if (norm_in) load_row(win, a.norm_in_w, d, lane);
+    load_row(w, a.norm_w + (size_t)r * d, d, lane);
+    if (prev < 0) {
+      if (pred) load_row(p, a.pred + (size_t)r * d, d, lane);
+      dtv = a.dt[r];
+    }
   }
   const float al = (float)a.pred_alpha;
   for (int q = prev + 1; q < s; ++q) {
@@ -232,6 +260,8 @@ __device__ __forceinline__ void region_rkv_body(const ic_region_args& a, float o
       rs[p] = sinf(th);
     }
   }
+  ChainRows<DCH> pre;
+  if (ROUTED) chain_rows<DCH>(a, r, lane, pre);  // in flight during the combines
   combine_rows();  // (after the weight rows were requested)
   if (ROUTED) __syncthreads();
   // Streams are walked 64 at a time from one ballot of the mask; the operands of the NEXT active
@@ -248,7 +278,7 @@ __device__ __forceinline__ void region_rkv_body(const ic_region_args& a, float o
       RowFrag<DCH> u1;
       float inv0, inv1;
       if (CHAIN) {
-        chain_prologue<DCH, ROUTED>(a, r, s, prev, lane, one_minus_alpha, u1, o.xv, inv0, inv1, o.steps, mrows);
+        chain_prologue<DCH, ROUTED>(a, r, s, prev, lane, one_minus_alpha, u1, o.xv, inv0, inv1, o.steps, mrows, pre);
       } else {
         prologue_row(a, row, lane, u1, o.xv, inv0, inv1);
       }
