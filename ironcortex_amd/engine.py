@@ -42,6 +42,8 @@ _F32, _I32, _U8 = torch.float32, torch.int32, torch.uint8
 FUSE_STEP = os.environ.get("IC_FUSE_STEP", "1") != "0"
 # IC_DEFER_SYNC=0: every loop waits for its last iteration's scores before it returns (A/B timing)
 DEFER_SYNC = os.environ.get("IC_DEFER_SYNC", "1") != "0"
+# IC_POLL_SYNC=0: hipStreamSynchronize at every outer iteration instead of polling the pinned score block
+POLL_SYNC = os.environ.get("IC_POLL_SYNC", "1") != "0"
 
 class StructImage:
     """Per-step images of a C argument struct.  Most pointer fields of a step's arguments are
@@ -805,6 +807,28 @@ class LoopEngine:
         u_mean = 0.0
         planned = False  # True when the previous iteration already ran the planner for both candidates
         settled = False
+        n_polled = 0
+        lsn = hs["buf"].get("ls_np")
+        if lsn is None:
+            lsn = hs["buf"]["ls_np"] = ls.numpy()  # the same pinned words, read without a tensor op
+        NAN = float("nan")
+
+        def wait_vhat(n: int) -> bool:
+            """Wait for the iteration's LAST kernel (the critic layer of the planner chain run for the n
+            candidates, which writes v_hat into the pinned score block) by polling those words for
+            the NaN the host left there, instead of a stream sync: the kernels before it finished
+            earlier on the same stream and their words are in host memory before these are (measured:
+            9.4 us launch-to-seen against 14.8 us with hipStreamSynchronize, scripts/poll_latency.py).
+            False after ~10 ms without an answer (a v_hat that IS NaN): the caller syncs instead."""
+            for _ in range(40000):
+                for c in range(n):
+                    v = lsn[40 + c]
+                    if v != v:
+                        break
+                else:
+                    return True
+            return False
+
         for k in range(K_inner):
             if k == 0 and zero_in and self._vhat0 is not None:
                 # every loop of a train_step starts from the shared all-zero state: the planner's
@@ -825,8 +849,9 @@ class LoopEngine:
                 if rc:
                     check(rc, "ic_steer_select/ic_gemv_chain")
             if k > 0 or not (zero_in and self._vhat0 is not None):
-                sync()
-                vals = ls.tolist()  # the one host sync of this outer iteration
+                if not (planned and POLL_SYNC and wait_vhat(n_polled)):
+                    sync()
+                vals = ls.tolist()  # the one host wait of this outer iteration
                 v_hat = vals[40]
                 if k == 0 and zero_in:
                     self._vhat0 = v_hat
@@ -853,6 +878,9 @@ class LoopEngine:
             # will there be a next iteration?  (should_halt only looks at this iteration's u_mean)
             planned = k + 1 < K_inner and not should_halt(None, u_mean, k, K_inner) and len(ids) <= 8
             ha.ws_mean = P["ws_prev"] if planned else None
+            if planned and POLL_SYNC:
+                n_polled = len(ids)
+                lsn[40:40 + n_polled] = NAN  # replaced by the last kernel of this iteration's chain (see wait_vhat)
             if not heads(ids, pars, sls):
                 raise RuntimeError("LoopEngine: branch inputs are not equally spaced (B_br > 2 is not supported)")
             verify(ids[0], len(ids), planned)
