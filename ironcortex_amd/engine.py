@@ -851,7 +851,7 @@ class LoopEngine:
             if k > 0 or not (zero_in and self._vhat0 is not None):
                 if not (planned and POLL_SYNC and wait_vhat(n_polled)):
                     sync()
-                vals = ls.tolist()  # the one host wait of this outer iteration
+                vals = lsn.tolist()  # the one host wait of this outer iteration (numpy view: no tensor op)
                 v_hat = vals[40]
                 if k == 0 and zero_in:
                     self._vhat0 = v_hat
