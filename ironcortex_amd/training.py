@@ -46,6 +46,24 @@ def make_negatives(clean_tokens: torch.Tensor, V: int):
 _MODULES = weakref.WeakKeyDictionary()  # model -> tuple of its modules (the tree is fixed after construction)
 
 
+_PARAMS = weakref.WeakKeyDictionary()  # model -> (number of registered parameters, tuple of them)
+
+
+def _parameters(model):
+    """tuple(model.parameters()) without walking the module tree on every step (0.2 ms); rebuilt
+    when a module's parameter registry changed size (FlatParams re-binds keep the count)."""
+    mods = _MODULES.get(model)
+    if mods is None:
+        mods = _MODULES[model] = tuple(model.modules())
+    n = 0
+    for mod in mods:
+        n += len(mod._parameters)
+    c = _PARAMS.get(model)
+    if c is None or c[0] != n or any(q is not r for q, r in zip(c[1][:4], model.parameters())):
+        c = _PARAMS[model] = (n, tuple(model.parameters()))
+    return c[1]
+
+
 def _ensure_training(model) -> None:
     """model.train(), skipped when every module is already in training mode: train() walks the
     tree and re-assigns the flag through nn.Module.__setattr__ on ~220 modules (0.3 ms per step)."""
@@ -179,7 +197,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     if dp is not None:
         dp.sync_grads(model)
     with torch.no_grad():
-        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        grads = [p.grad for p in _parameters(model) if p.grad is not None]
         grad_norm = torch.stack(torch._foreach_norm(grads)).pow(2).sum().sqrt() if grads else torch.tensor(0.0, device=device)
         # Hebbian nudges on edges whose two ends were active in a positive sample (training.py:147-156,240-243)
         if gains is not None and model.router.E > 0:
