@@ -858,7 +858,10 @@ class LoopEngine:
             else:
                 v_hat = self._vhat0
             if k > 0:
-                top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
+                if len(branches) == 2:  # (score descending, index ascending)
+                    top = [1, 0] if vals[1] > vals[0] else [0, 1]
+                else:
+                    top = sorted(range(len(branches)), key=lambda i: (-vals[i], i))[:min(B_br, 2)]
                 if planned:
                     v_hat = vals[40 + top[0]]  # the winner's, from the chain run for every candidate
                 branches = [branches[i] for i in top]
