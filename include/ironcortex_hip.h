@@ -399,12 +399,6 @@ int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g_mean, const 
  * score below, in the same launch when the chain is small. */
 int ic_verify_score(const ic_gemv_desc* descs, int32_t n, const float* stats, float* score,
                     ic_stream_t stream);
-/* Chains of 2..6 layers run as ONE launch over a few workgroups with a grid barrier between layers
- * (default OFF: measured slower than one launch per layer on MI355X, see heads.hip).  The barrier's wait is bounded; ic_gemv_coop_failed()
- * returns 1 if a chain ever gave up on the current device (synchronises the device).  One chain
- * at a time per device: the barrier's ticket counter is shared. */
-int ic_gemv_coop_enable(int on);
-int ic_gemv_coop_failed(void);
 /* (batched descriptors: batch b reads stats + 4*b and writes score + b) */
 /* score = 0.6*stats[2] + 0.2*(-energy) + 0.2*stats[1]   (model.py:431-438) */
 int ic_branch_score(const float* stats, const float* energy, float* score, ic_stream_t stream);

@@ -266,97 +266,6 @@ __global__ __launch_bounds__(1024) void k_gemv_chain1(ChainArgs c) {
   }
 }
 
-// A chain of GEMVs as ONE launch over a few workgroups with a grid barrier between layers.
-// A layer-per-launch chain pays ~4.5 us per layer (launch ramp + gap) for ~1 us of streaming; one
-// workgroup for the whole chain (above) is bounded by a single CU's ~25 GB/s.  Here kCoopWGs
-// workgroups (all resident at once: far fewer than CUs) split every layer's rows and meet at a
-// ticket barrier: device-scope release before the ticket, acquire after the wait, so the next
-// layer's input -- written by other workgroups, possibly behind another XCD's L2 -- is read fresh.
-// The wait is bounded: a workgroup that never sees its peers gives up, raises g_coop_err and
-// leaves, so the grid always drains.
-constexpr int kCoopWGs = 32;
-__device__ unsigned long long g_coop_bar = 0;  // tickets taken so far (a multiple of the grid size between launches)
-__device__ int g_coop_err = 0;
-
-__device__ __forceinline__ bool grid_barrier(int nwg) {
-  __syncthreads();
-  __shared__ int ok;
-  if (threadIdx.x == 0) {
-    // layer outputs are written / read with device-scope atomic accesses (write-through, L2 bypass),
-    // and the barrier above has waited for this workgroup's stores: no cache-wide fence is needed
-    const unsigned long long old = __hip_atomic_fetch_add(&g_coop_bar, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long target = (old / (unsigned long long)nwg + 1ULL) * (unsigned long long)nwg;
-    int good = 0;
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-      if (__hip_atomic_load(&g_coop_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
-        good = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (!good) atomicExch(&g_coop_err, 1);
-    ok = good;
-  }
-  __syncthreads();
-  return ok != 0;
-}
-
-__global__ __launch_bounds__(256) void k_gemv_coop(ChainArgs c) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nwg = gridDim.x, gw = blockIdx.x * 4 + wave, nw = nwg * 4;
-  auto ld = [](const float* p) {  // an input another workgroup of this launch may have written
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  for (int L = 0; L < c.n; ++L) {
-    const ic_gemv_desc& g0 = c.d[L];
-    const int cols = g0.n0 + g0.n1 + g0.n2;
-    const int nb = g0.nbatch > 1 ? g0.nbatch : 1;
-    const int pairs = (g0.rows + 1) / 2;
-    const bool last = L == c.n - 1;
-    for (int item = gw; item < pairs * nb; item += nw) {
-      const int bi = item / pairs, row0 = (item % pairs) * 2;
-      const ic_gemv_desc g = gemv_batch(g0, bi);
-      const bool two = row0 + 1 < g.rows;
-      const float* w0p = g.W + (size_t)row0 * cols;
-      const float* w1p = w0p + (two ? cols : 0);
-      float mean = 0.f, rstd = 1.f;
-      if (g.ln_g) {  // torch.nn.LayerNorm: biased variance (same order of operations as k_gemv_reg)
-        float sm = 0.f;
-        for (int cc = lane; cc < cols; cc += 64)
-          sm += cc < g.n0 ? ld(g.x0 + cc) : (cc < g.n0 + g.n1 ? ld(g.x1 + cc - g.n0) : ld(g.x2 + cc - g.n0 - g.n1));
-        mean = wave_sum(sm) / (float)cols;
-        float q = 0.f;
-        for (int cc = lane; cc < cols; cc += 64) {
-          const float v = cc < g.n0 ? ld(g.x0 + cc) : (cc < g.n0 + g.n1 ? ld(g.x1 + cc - g.n0) : ld(g.x2 + cc - g.n0 - g.n1));
-          const float t = v - mean;
-          q += t * t;
-        }
-        rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + g.ln_eps);
-      }
-      float a0 = 0.f, a1 = 0.f;
-#pragma unroll 8
-      for (int cc = lane; cc < cols; cc += 64) {
-        float v = cc < g.n0 ? ld(g.x0 + cc) : (cc < g.n0 + g.n1 ? ld(g.x1 + cc - g.n0) : ld(g.x2 + cc - g.n0 - g.n1));
-        if (g.ln_g) v = (v - mean) * rstd * g.ln_g[cc] + g.ln_b[cc];
-        a0 = fmaf(w0p[cc], v, a0);
-        a1 = fmaf(w1p[cc], v, a1);
-      }
-      a0 = wave_sum(a0);
-      a1 = wave_sum(a1);
-      if (lane == 0) {
-        const float o0 = apply_act(a0 + (g.b ? g.b[row0] : 0.f), g.act);
-        __hip_atomic_store(g.y + row0, o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (two)
-          __hip_atomic_store(g.y + row0 + 1, apply_act(a1 + (g.b ? g.b[row0 + 1] : 0.f), g.act), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        if (last && c.score && row0 == 0)  // the verifier's last layer: energy -> branch score (model.py:431-438)
-          c.score[bi] = 0.6f * c.stats[4 * bi + 2] + 0.2f * (-o0) + 0.2f * c.stats[4 * bi + 1];
-      }
-    }
-    if (!last && !grid_barrier(nwg)) return;
-  }
-}
-
 // ONE launch for the heads of an inner step.  blockIdx.y selects the work:
 //   0            z = [gate; facets] . H[motor] + bias                    (heads.py:96-119)
 //   1 + r        region head r on H[r], active regions other than motor  (model.py:311-318)
@@ -750,24 +659,6 @@ __global__ __launch_bounds__(256) void k_steer_select(ic_steer_args a) {
 
 }  // namespace
 
-// Off by default: measured on MI355X, a 6-layer chain costs ~31 us this way against ~27 us as six
-// launches (a ticket barrier across XCDs is two device-scope atomic round trips, ~4 us, no cheaper
-// than a kernel boundary); kept as an option and as the measured record of the experiment.
-static bool g_ic_coop_chains = false;
-
-extern "C" int ic_gemv_coop_enable(int on) {
-  g_ic_coop_chains = on != 0;
-  return IC_OK;
-}
-
-// 1 if a cooperative chain ever gave up waiting at its grid barrier on the current device
-// (its outputs are then invalid).  Synchronises the device.
-extern "C" int ic_gemv_coop_failed(void) {
-  int v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_coop_err), sizeof(int)) != hipSuccess) return -1;
-  return v;
-}
-
 static int check_gemv(const ic_gemv_desc& g, int i, const char* who) {
   const int cols = g.n0 + g.n1 + g.n2;
   IC_REQUIRE(g.W && g.y && g.rows > 0, "%s[%d]: NULL W/y or rows=%d", who, i, g.rows);
@@ -799,15 +690,6 @@ static int run_chain(const ic_gemv_desc* descs, int n, const float* stats, float
     c.stats = stats;
     c.score = score;
     IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_chain1, dim3(1), dim3(1024), 0, st, c));
-    return IC_OK;
-  }
-  if (n >= 2 && n <= 6 && g_ic_coop_chains) {  // one launch, grid barrier between layers
-    ChainArgs c;
-    for (int i = 0; i < n; ++i) c.d[i] = descs[i];
-    c.n = n;
-    c.stats = stats;
-    c.score = score;
-    IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_coop, dim3(kCoopWGs), dim3(256), 0, st, c));
     return IC_OK;
   }
   for (int i = 0; i < n; ++i) {

@@ -202,6 +202,20 @@ class LoopEngine:
         if self._arena is not None:
             self._arena.reset()
 
+    def new_step(self) -> None:
+        """train_step's first call.  A backward pass that raised (OOM, an ic_* error code, a user
+        hook) never runs the coordinator's end-of-pass callback; tape slots booked by a
+        grad-enabled forward that was never differentiated are never reclaimed.  A train_step owns
+        its whole forward/backward, so at its start both are leftovers: clear them, then reset()."""
+        m = self.model
+        m._coord.abort()
+        self._pass = None
+        self._batch = None
+        m.bank.tape.reset()
+        if m.router._tape is not None:
+            m.router._tape.reset()
+        self.reset()
+
     def _rescue_state(self) -> None:
         self.resolve_pending()
         if not self._state_in_arena:

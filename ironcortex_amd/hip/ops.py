@@ -63,6 +63,14 @@ class GradCoordinator:
         finally:
             self._pending = False
 
+    def abort(self) -> bool:
+        """A backward pass that raised never reaches its end-of-pass callback, which would leave
+        _pending set for good (every later pass would skip begin_pass() and never publish its
+        gradients).  Called at a known boundary -- the start of a train_step / LoopEngine.reset():
+        no pass can be in flight there, so a set flag is a stale one.  Returns True if it was."""
+        stale, self._pending = self._pending, False
+        return stale
+
 
 class Tape:
     """Per-step gradient vectors kept until the end of the backward pass.

@@ -101,7 +101,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     focus_all = torch.cat([torch.zeros_like(focus_neg, dtype=torch.bool), focus_neg], dim=0)
     # no loss below back-propagates through the inner-step logits / workspace (training.py:120-231):
     # the loops may run on the LoopEngine (one autograd node per loop)
-    model.engine.reset()
+    model.engine.new_step()
     model._logits_detached = True
     model.router.hold_bias = True  # every loop of this step feeds the one backward pass below
     try:

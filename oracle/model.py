@@ -429,6 +429,23 @@ def oracle_train_step(model: OracleReasoner, optimizer, clean_tokens: torch.Tens
     return (out, grads) if return_grads else out
 
 
+@torch.no_grad()
+def oracle_evaluate_perplexity(model: OracleReasoner, tokens: torch.Tensor) -> Dict[str, float]:
+    """evaluation.py:14-52: prefix-outer teacher forcing over the whole [B,t] batch, all-False focus."""
+    model.eval()
+    B, T = tokens.shape
+    if T < 2:
+        raise ValueError("tokens must have length >= 2 for evaluation")
+    ce_sum, n_pred = 0.0, 0
+    for t in range(1, T):
+        focus = torch.zeros(B, t, dtype=torch.bool)
+        _, _, logits, _, _, _ = model.reasoning_loop_batch(tokens[:, :t], model.cfg.K_inner, focus)
+        ce_sum += F.nll_loss(F.log_softmax(logits, dim=-1), tokens[:, t], reduction="sum").item()
+        n_pred += B
+    ce = ce_sum / max(1, n_pred)
+    return {"cross_entropy": ce, "perplexity": float(math.exp(ce))}
+
+
 def build(cfg: CortexConfig, cls=OracleReasoner):
     from .hotpath import hex_axial_coords, hex_neighbors
     return cls(hex_neighbors(cfg.R), hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)

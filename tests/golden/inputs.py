@@ -127,3 +127,12 @@ def kwta_rows(seed: int, d: int) -> torch.Tensor:
 
 
 GATE_R = [4, 7, 10, 36, 64, 512]
+
+
+def synth_tensor(idx: int, shape, mean: float, std: float) -> torch.Tensor:
+    """A large parameter of a full-size model case: uniform with the recorded mean / standard
+    deviation of the reference's own initialisation (the 10-40 M-parameter state_dicts of the
+    full-size cases are regenerated from ~150 (index, mean, std) triples instead of being stored)."""
+    g = torch.Generator().manual_seed(77000 + int(idx))
+    u = torch.rand(tuple(int(x) for x in shape), generator=g) * 2 - 1
+    return u * float(std * math.sqrt(3.0)) + float(mean)

@@ -318,8 +318,98 @@ def model_fixture():
         save(f"model_{name}.npz", blob)
 
 
+# ------------------------------------------------------------------ evaluate_perplexity (evaluation.py:14-52)
+from tests.golden.make_eval import EVAL_T  # noqa: E402
+
+
+def eval_fixture():
+    """Reference evaluate_perplexity on the small whole-model cases (state_dicts of model_*.npz)."""
+    from ironcortex import CortexConfig, CortexReasoner
+    from ironcortex.evaluation import evaluate_perplexity
+    blob = {}
+    for name, kw in MODEL_CASES.items():
+        gold = np.load(os.path.join(HERE, f"model_{name}.npz"))
+        cfg = CortexConfig(**kw)
+        torch.manual_seed(5)
+        model = CortexReasoner(hex_neighbors(cfg.R), hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
+        model.load_state_dict({k[3:]: torch.as_tensor(gold[k]) for k in gold.files if k.startswith("sd.")})
+        tokens = (gi.det(31, MODEL_B, MODEL_T, kind="rand") * (cfg.V - 1)).long()[:, :EVAL_T]
+        out = evaluate_perplexity(model, tokens, torch.device("cpu"))
+        blob[name + ".cross_entropy"] = np.array(out["cross_entropy"]); blob[name + ".perplexity"] = np.array(out["perplexity"])
+        blob[name + ".num"] = npy(torch.stack([r.state_num for r in model.regions]))  # state carried across the calls
+    save("eval.npz", blob)
+
+
+# ------------------------------------------------------------------ F9/F10 at full size
+def bigmodel_fixture():
+    """The exact bench model (10M script config, T=256) and the default script config (R=36, d=256,
+    T=64).  The state_dict is the reference's own initialisation with every large tensor replaced by
+    a seeded uniform of the same mean / std (tests/golden/inputs.py::synth_tensor), so that it can be
+    regenerated instead of stored; large gradients are stored as two probe projections."""
+    import copy
+    import random
+    from ironcortex import CortexConfig, CortexReasoner, LossWeights, train_step
+    from tests.model_cases import BIG_CASES, big_inputs, grad_probes
+    for name, (kw, B, T) in BIG_CASES.items():
+        torch.manual_seed(11); random.seed(11)
+        cfg = CortexConfig(**kw)
+        model = CortexReasoner(hex_neighbors(cfg.R), hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
+        if name == "r36":  # tie-free gate scores from the first inner step on
+            model.gate.gain_ema.copy_(gi.det(8100, cfg.R, scale=0.2))
+            model.gate.homeo.copy_(gi.det(8101, cfg.R, scale=0.05))
+        blob, new = {}, {}
+        sd = model.state_dict()
+        blob["sd_order"] = np.array(list(sd.keys()))
+        for idx, (k, v) in enumerate(sd.items()):
+            if v.is_floating_point() and v.numel() > 4096:
+                if bool(((v == 0) | (v == 1)).all()):  # k-hot token codes (sdr.py:14-29)
+                    blob["sdbits." + k] = np.packbits(npy(v).astype(np.uint8).reshape(-1))
+                    blob["sdshape." + k] = np.array(v.shape)
+                    new[k] = v.clone()
+                else:
+                    mean, std = float(v.mean()), float(v.std())
+                    blob["sdgen." + k] = np.array([idx, mean, std, *v.shape], dtype=np.float64)
+                    new[k] = gi.synth_tensor(idx, v.shape, mean, std)
+            else:
+                blob["sd." + k] = npy(v)
+                new[k] = v.clone()
+        model.load_state_dict(new)
+        tokens, focus = big_inputs(name)
+        probe = copy.deepcopy(model)
+        with torch.no_grad():
+            H, m, logits, traces, en, ent = probe.reasoning_loop_batch(tokens, cfg.K_inner, focus)
+        blob["loop.H"] = npy(H); blob["loop.mask"] = npy(m); blob["loop.logits"] = npy(logits)
+        blob["loop.trace0"] = npy(torch.stack(traces[0])); blob["loop.energy"] = npy(en)
+        blob["loop.num"] = npy(torch.stack([r.state_num for r in probe.regions]))
+        blob["loop.pred"] = npy(torch.stack([r.pred for r in probe.regions]))
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        torch.manual_seed(77); random.seed(77)
+        for step in range(2):
+            out = train_step(model, opt, tokens, LossWeights(), torch.device("cpu"))
+            for k, v in out.items():
+                blob[f"step{step}.{k}"] = np.array(v, dtype=np.float64)
+            if step == 0:
+                names = []
+                for n, p in model.named_parameters():
+                    if p.grad is None:
+                        continue
+                    names.append(n)
+                    blob["gnorm." + n] = np.array(float(p.grad.norm()))
+                    if p.numel() <= 4096:
+                        blob["grad." + n] = npy(p.grad)
+                    elif p.dim() == 2:
+                        pc, pr = grad_probes(p.shape[1], p.shape[0])
+                        blob["gp." + n] = npy(p.grad @ pc); blob["gq." + n] = npy(pr @ p.grad)
+                blob["grad_names"] = np.array(names)
+        blob["final.gain_ema"] = npy(model.gate.gain_ema); blob["final.homeo"] = npy(model.gate.homeo)
+        blob["final.tau"] = npy(torch.stack([f.tau for f in model.reg_ff]))
+        for n, p in model.named_parameters():
+            blob["pnorm." + n] = np.array(float(p.detach().norm()))
+        save(f"model_{name}.npz", blob)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["region", "chain", "kwta", "gate", "router", "wiring", "model"]
+    which = sys.argv[1:] or ["region", "chain", "kwta", "gate", "router", "wiring", "model", "bigmodel", "eval"]
     for w in which:
         globals()[w + "_fixture"]()

@@ -18,15 +18,56 @@ MODEL_CASES = {
 }
 MODEL_B, MODEL_T = 2, 24
 
+# Full-size cases: the exact bench model (reference train_tiny_shakespeare_10m.py:32-48)
+# at the bench's T, and the default script config (train_tiny_shakespeare.py:59-67) with
+# gate.gain_ema / homeo seeded tie-free (Gate.select_k's order on exact ties is torch.argsort's).
+# name -> (CortexConfig kwargs, B, T)
+BIG_CASES = {
+    "bench10m": (dict(R=10, d=256, V=256, K_inner=8, B_br=2, k_active=8, max_T=512,
+                      enable_adaptive_filter_dynamics=True, enable_precision_routed_messages=True,
+                      enable_radial_tangential_updates=True, enable_afa_attention=True,
+                      enable_ff_energy_alignment=True, enable_energy_verifier=True,
+                      enable_forward_forward=True, debug_metrics_every_n_steps=2), 2, 256),
+    "r36": (dict(R=36, d=256, V=256, K_inner=8, B_br=2, k_active=8, max_T=512), 2, 64),
+}
+
+
+def big_inputs(name):
+    kw, B, T = BIG_CASES[name]
+    tokens = (gi.det(31, B, T, kind="rand") * (kw["V"] - 1)).long()
+    focus = gi.det(32, B, T, kind="rand") < 0.3
+    return tokens, focus
+
 
 def load_case(name):
     from ironcortex_amd.config import CortexConfig
     gold = np.load(os.path.join(GOLD, f"model_{name}.npz"))
+    if name in BIG_CASES:
+        cfg = CortexConfig(**BIG_CASES[name][0])
+        order = gold["sd_order"].tolist()
+        sd = {}
+        for k in order:
+            if "sd." + k in gold.files:
+                sd[k] = torch.as_tensor(gold["sd." + k])
+            elif "sdbits." + k in gold.files:
+                shape = tuple(int(x) for x in gold["sdshape." + k])
+                n = int(np.prod(shape))
+                sd[k] = torch.as_tensor(np.unpackbits(gold["sdbits." + k])[:n].reshape(shape).astype(np.float32))
+            else:
+                spec = gold["sdgen." + k]  # [index, mean, std, *shape]
+                sd[k] = gi.synth_tensor(int(spec[0]), [int(x) for x in spec[3:]], float(spec[1]), float(spec[2]))
+        tokens, focus = big_inputs(name)
+        return gold, cfg, sd, tokens, focus
     cfg = CortexConfig(**MODEL_CASES[name])
     sd = {k[3:]: torch.as_tensor(gold[k]) for k in gold.files if k.startswith("sd.")}
     tokens = (gi.det(31, MODEL_B, MODEL_T, kind="rand") * (cfg.V - 1)).long()
     focus = gi.det(32, MODEL_B, MODEL_T, kind="rand") < 0.3
     return gold, cfg, sd, tokens, focus
+
+
+def grad_probes(n_cols: int, n_rows: int):
+    """Probe vectors for the stored projections of large matrix gradients (g @ p, q @ g)."""
+    return gi.det(4101, n_cols), gi.det(4102, n_rows)
 
 
 def seed_train():

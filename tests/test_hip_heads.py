@@ -292,49 +292,6 @@ def test_strided_streams_equal_separate_calls():
         close(both["ls"][48 + s_], ls[48].cpu(), rtol=1e-5, atol=1e-6, what="energy")
 
 
-def test_cooperative_chain_equals_layer_by_layer():
-    """ic_gemv_chain / ic_verify_score as one cooperative launch (grid barrier between layers) ==
-    one launch per layer, bit for bit; the bounded barrier never gave up."""
-    from ironcortex_amd import hip
-    cfg, prod, _ = build_pair("allflags")
-    R, d, V = cfg.R, cfg.d, cfg.V
-    dev = torch.device(DEV)
-    L, st = hip.lib(), hip.stream_handle()
-    hs_ = prod.engine._heads_setup(dev)
-    steer, ver, buf = hs_["steer"], hs_["ver"], hs_["buf"]
-    g = torch.Generator().manual_seed(11)
-    Hc = (torch.randn(2, R, d, generator=g) * (torch.rand(2, R, d, generator=g) < 0.3)).to(DEV)
-    outs = {}
-    for mode in (0, 1, 1, 0):
-        hip.check(L.ic_gemv_coop_enable(ctypes.c_int(mode)), "coop_enable")
-        buf["ws_prev"].copy_(torch.randn(d, generator=torch.Generator().manual_seed(5)).to(DEV))
-        for k in ("p_h", "p", "g_h", "g", "c_h"):
-            buf[k].zero_()
-        buf["ls"].zero_()
-        buf["probs"].copy_(torch.softmax(torch.randn(2, V, generator=torch.Generator().manual_seed(6)), -1).to(DEV))
-        buf["h1"].zero_(); buf["h2"].zero_()
-        hip.check(L.ic_gemv_chain(steer, 6, st), "chain")
-        ls = buf["ls"]
-        stats = torch.tensor([0.0, -1.5, 0.25, 0.0, 0.0, -2.0, 0.5, 0.0], device=DEV)
-        ls[8:16].copy_(stats)
-        ver[0].x0 = Hc.data_ptr() + (R - 1) * d * 4
-        ver[2].y = ls.data_ptr() + 48 * 4
-        for g_ in ver:
-            g_.nbatch = 2
-        hip.check(L.ic_verify_score(ver, 3, ls.data_ptr() + 32, ls.data_ptr(), st), "verify")
-        torch.cuda.synchronize()
-        cur = {k: buf[k].clone() for k in ("p_h", "p", "g_h", "g", "c_h", "ls", "h1", "h2")}
-        if mode in outs:
-            for k in cur:
-                assert torch.equal(cur[k], outs[mode][k]), ("not reproducible", mode, k)
-        outs[mode] = cur
-    hip.check(L.ic_gemv_coop_enable(ctypes.c_int(0)), "coop_enable")  # the library default
-    assert L.ic_gemv_coop_failed() == 0
-    for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[1][k]), ("cooperative chain differs from layer-by-layer", k)
-    assert float(outs[1]["ls"][40]) != 0.0 and float(outs[1]["ls"][0]) != 0.0
-
-
 def test_planner_for_both_candidates_in_the_verifier_launches():
     """The engine's merged launches (ic_gemv_multi: verifier layer i next to planner layer i, both
     batched over the two branches) == the two chains run separately, bit for bit."""

@@ -1,16 +1,19 @@
 """GPU whole-model parity: the product CortexReasoner/train_step (HIP hot path) against the
 REAL reference's recorded outputs, from the same state_dict, tokens and seeds.
 
-Tolerances: states/logits rtol 1e-4 atol 1e-5; the 15 train_step metrics rel 1e-3 (they sum
-thousands of fp32 terms through 24-64 chained inner steps); gradient norms rel 2e-3.
-Region selections and KWTA winners must be identical."""
+Cases: three small configs (d=32) and two FULL-SIZE ones -- the exact bench model (10M script
+config, R=10, d=256, T=256) and the default script config (R=36, d=256, T=64).  Tolerances are
+the TOL_* constants below (a few 1e-6, set from the errors observed on MI355X and logged by
+tests/parity_log.py).  Region selections and KWTA winners must be identical."""
 import copy
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from tests.model_cases import MODEL_CASES, load_case, seed_train
+from tests import parity_log as PL
+from tests.model_cases import BIG_CASES, MODEL_CASES, grad_probes, load_case, seed_train
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -26,8 +29,23 @@ def build(cfg, sd):
     return model.to(DEV)
 
 
+ALL_CASES = list(MODEL_CASES) + list(BIG_CASES)
+# Tolerances (relative to the reference tensor's largest magnitude; see tests/parity_log.py).
+# TOL_* are ~3x the worst error OBSERVED on MI355X over all cases (profiles/r02_parity_errors.jsonl);
+# the north_star asks for "about 1e-5 relative" and every forward quantity meets it.
+# Observed worst (round 2, all five cases, both host paths): states 7.0e-7, metrics 9.6e-7, gradient
+# norms 1.3e-5 (verify.net.1.weight, a PyTorch MLP off the hot path; hot-path parameters <= 2e-6),
+# gradient tensors / probes 5.3e-6, gain_ema 4.8e-7, tau 2.3e-6, parameter norms 1.2e-6.
+TOL_STATE = 3e-6     # region states, traces, logits, energies after up to 64 chained inner steps
+TOL_METRIC = 5e-6    # the 15 train_step metrics
+TOL_GNORM = 4e-5     # per-parameter gradient norms
+TOL_GRAD = 2e-5      # gradient tensors / probe projections
+TOL_BUF = 1e-5       # gain_ema, tau after two steps
+TOL_PNORM = 5e-6     # parameter norms after two AdamW steps
+
+
 @pytest.mark.parametrize("engine", [True, False], ids=["engine", "general"])
-@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_reasoning_loop_vs_reference(name, engine):
     """engine: the LoopEngine (ironcortex_amd/engine.py); general: one autograd Function per call."""
     gold, cfg, sd, tokens, focus = load_case(name)
@@ -37,16 +55,19 @@ def test_reasoning_loop_vs_reference(name, engine):
         H, m, logits, traces, en, ent = model.reasoning_loop_batch(tokens.to(DEV), cfg.K_inner, focus.to(DEV))
     assert np.array_equal(m.cpu().numpy(), gold["loop.mask"])
     assert np.array_equal(H.cpu().numpy() != 0, gold["loop.H"] != 0)
-    close = lambda a, b: torch.testing.assert_close(a.cpu(), torch.as_tensor(b), rtol=1e-4, atol=1e-5)
-    close(H, gold["loop.H"]); close(logits, gold["loop.logits"]); close(torch.stack(traces[0]), gold["loop.trace0"])
-    close(en, gold["loop.energy"])
-    close(model.bank.num[0], gold["loop.num"]); close(model.bank.pred[0], gold["loop.pred"])
+    tag = f"loop/{name}/{'engine' if engine else 'general'}"
+    PL.check(tag, "H", H, gold["loop.H"], TOL_STATE); PL.check(tag, "logits", logits, gold["loop.logits"], TOL_STATE)
+    PL.check(tag, "trace0", torch.stack(traces[0]), gold["loop.trace0"], TOL_STATE)
+    PL.check(tag, "energy", en, gold["loop.energy"], TOL_STATE)
+    PL.check(tag, "num", model.bank.num[0], gold["loop.num"], TOL_STATE)
+    PL.check(tag, "pred", model.bank.pred[0], gold["loop.pred"], TOL_STATE)
     # the drop-in attribute views agree with the bank
-    close(model.regions[0].state_num, gold["loop.num"][0])
+    PL.check(tag, "num", model.regions[0].state_num, gold["loop.num"][0], TOL_STATE)
+    PL.flush(tag)
 
 
 @pytest.mark.parametrize("engine", [True, False], ids=["engine", "general"])
-@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_two_train_steps_vs_reference(name, engine):
     import ironcortex_amd as ic
     gold, cfg, sd, tokens, focus = load_case(name)
@@ -54,31 +75,36 @@ def test_two_train_steps_vs_reference(name, engine):
     model.engine.enabled = engine
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     seed_train()
+    tag = f"train/{name}/{'engine' if engine else 'general'}"
     for step in range(2):
         out = ic.train_step(model, opt, tokens.to(DEV), ic.LossWeights(), torch.device(DEV))
         for k in KEYS:
-            ref = float(gold[f"step{step}.{k}"])
-            assert out[k] == pytest.approx(ref, rel=1e-3, abs=1e-4), (step, k, out[k], ref)
+            PL.check(tag, f"metric:{step}.{k}", out[k], float(gold[f"step{step}.{k}"]), TOL_METRIC, floor=1e-5)
         if step == 0:
             names = set(gold["grad_names"].tolist())
-            got = {n for n, p in model.named_parameters() if p.grad is not None}
+            params = dict(model.named_parameters())
+            got = {n for n, p in params.items() if p.grad is not None}
             assert got == names, (sorted(got - names)[:8], sorted(names - got)[:8])
-            for n, p in model.named_parameters():
-                if p.grad is not None:
-                    assert float(p.grad.norm()) == pytest.approx(float(gold["gnorm." + n]), rel=2e-3, abs=1e-5), n
+            for n in names:
+                PL.check(tag, f"gnorm:{n}", float(params[n].grad.norm()), float(gold["gnorm." + n]), TOL_GNORM, floor=1e-6)
             for k in gold.files:
                 if k.startswith("grad."):
-                    g = dict(model.named_parameters())[k[5:]].grad
-                    torch.testing.assert_close(g.cpu(), torch.as_tensor(gold[k]), rtol=2e-3, atol=2e-5)
-    torch.testing.assert_close(model.gate.gain_ema.cpu(), torch.as_tensor(gold["final.gain_ema"]), rtol=1e-3, atol=1e-5)
-    torch.testing.assert_close(model.gate.homeo.cpu(), torch.as_tensor(gold["final.homeo"]), rtol=1e-5, atol=1e-7)
-    torch.testing.assert_close(torch.stack([f.tau for f in model.reg_ff]).cpu(), torch.as_tensor(gold["final.tau"]), rtol=1e-3, atol=1e-5)
+                    PL.check(tag, f"grad:{k[5:]}", params[k[5:]].grad, gold[k], TOL_GRAD, floor=1e-6)
+                elif k.startswith("gp."):
+                    g = params[k[3:]].grad.cpu()
+                    pc, pr = grad_probes(g.shape[1], g.shape[0])
+                    PL.check(tag, f"gprobe:{k[3:]}", g @ pc, gold[k], TOL_GRAD, floor=1e-6)
+                    PL.check(tag, f"gprobe:{k[3:]}", pr @ g, gold["gq." + k[3:]], TOL_GRAD, floor=1e-6)
+    PL.check(tag, "gain_ema", model.gate.gain_ema, gold["final.gain_ema"], TOL_BUF)
+    PL.check(tag, "homeo", model.gate.homeo, gold["final.homeo"], 1e-5)
+    PL.check(tag, "tau", torch.stack([f.tau for f in model.reg_ff]), gold["final.tau"], TOL_BUF)
     for n, p in model.named_parameters():
         # a gradient that is analytically zero (e.g. the key bias of a softmax attention) is pure
         # rounding noise; Adam turns its SIGN into a +-lr step, so such parameters are not comparable
         if ("gnorm." + n) in gold.files and float(gold["gnorm." + n]) < 1e-6:
             continue
-        assert float(p.detach().norm()) == pytest.approx(float(gold["pnorm." + n]), rel=1e-4, abs=1e-6), n
+        PL.check(tag, f"pnorm:{n}", float(p.detach().norm()), float(gold["pnorm." + n]), TOL_PNORM, floor=1e-6)
+    PL.flush(tag)
 
 
 def test_checkpoint_roundtrip(tmp_path):
@@ -93,11 +119,33 @@ def test_checkpoint_roundtrip(tmp_path):
     ic.save_checkpoint(model, opt, 3, path)
     model2 = build(cfg, sd)
     opt2 = torch.optim.AdamW(model2.parameters(), lr=1e-3)
-    assert ic.load_checkpoint(model2, opt2, path, device=torch.device(DEV)) == 3
+    # the reference's call (train_tiny_shakespeare.py:95, tests/test_checkpoint.py:35)
+    assert ic.load_checkpoint(path, model2, opt2, map_location=torch.device(DEV)) == 3
+    assert ic.load_checkpoint(path) == 3  # model and optimizer are optional (checkpoint.py:37-42)
     for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert torch.equal(a, b), k
     # the arena layout survived load_state_dict: kernels see the loaded weights
     assert model2.regions[1].r_lin.weight.data_ptr() == model2.bank.flat.stacked("W")[4].data_ptr()
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+def test_evaluate_perplexity_vs_reference(name):
+    """reference evaluation.py:14-52 run by tests/golden/make_fixtures.py::eval_fixture: same dict,
+    same values, region state carried across the T-1 calls the same way; ValueError for T < 2."""
+    import ironcortex_amd as ic
+    from tests.golden.make_eval import EVAL_T
+    gold, cfg, sd, tokens, focus = load_case(name)
+    ev = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval.npz"))
+    model = build(cfg, sd)
+    out = ic.evaluate_perplexity(model, tokens[:, :EVAL_T], torch.device(DEV))
+    assert set(out) == {"cross_entropy", "perplexity"}
+    tag = f"eval/{name}"
+    PL.check(tag, "cross_entropy", out["cross_entropy"], float(ev[name + ".cross_entropy"]), TOL_METRIC)
+    PL.check(tag, "perplexity", out["perplexity"], float(ev[name + ".perplexity"]), TOL_METRIC)
+    PL.check(tag, "num", model.bank.num[0], ev[name + ".num"], TOL_STATE)
+    PL.flush(tag)
+    with pytest.raises(ValueError):
+        ic.evaluate_perplexity(model, tokens[:, :1], torch.device(DEV))
 
 
 def test_generation_smoke():
@@ -140,6 +188,55 @@ def test_batched_backward_equals_loop_by_loop(name):
             torch.testing.assert_close(g, grads[1][n], rtol=1e-4, atol=1e-6 * max(1.0, float(grads[1][n].abs().max())), msg=n)
     for k in KEYS:
         assert metrics[0][k] == pytest.approx(metrics[1][k], rel=1e-5, abs=1e-6), k
+
+
+def test_train_step_recovers_after_a_failed_backward():
+    """A backward pass that raises must not poison the next train_step (GradCoordinator
+    kept _pending set, so later passes skipped begin_pass() and never published gradients)."""
+    import ironcortex_amd as ic
+    gold, cfg, sd, tokens, focus = load_case("allflags")
+    model = build(cfg, sd)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    eng = model.engine
+    orig = eng.backward_batch
+
+    def boom(bt, gH):
+        eng.model._coord.begin()  # the pass has started when the failure comes
+        raise RuntimeError("injected")
+
+    eng.backward_batch = boom
+    seed_train()
+    with pytest.raises(RuntimeError, match="injected"):
+        ic.train_step(model, opt, tokens.to(DEV), ic.LossWeights(), torch.device(DEV))
+    assert model._coord._pending  # the stale flag the advisor described
+    eng.backward_batch = orig
+    out = ic.train_step(model, opt, tokens.to(DEV), ic.LossWeights(), torch.device(DEV))
+    assert not model._coord._pending and model.bank.tape.pos == 0 and eng._pass is None
+    got = {n for n, p in model.named_parameters() if p.grad is not None}
+    assert {"regions.0.r_lin.weight", "regions.0.norm.weight", "norm_in.weight", "router.beta_cos"} <= got
+    assert float(model.regions[0].r_lin.weight.grad.abs().sum()) > 0 and out["grad_norm"] > 0
+    # and the step after that equals the same step of a model that never failed
+    ref = build(cfg, sd)
+    for k in ("num", "den", "var", "pred", "radius", "radius_var", "surprise", "dt"):
+        setattr(ref.bank, k, getattr(model.bank, k).clone())
+    ref.bank.S = model.bank.S
+    ref.work.slots = model.work.slots.clone()
+    ref.load_state_dict(model.state_dict())
+    for a, b in zip(ref.reg_ff, model.reg_ff):
+        a.tau = b.tau.clone()
+    ref._train_step, ref._lambda_s = model._train_step, model._lambda_s
+    for k in ("E_pos_mean", "E_neg_mean"):  # non-persistent buffers
+        if hasattr(model, k):
+            setattr(ref, k, getattr(model, k).clone())
+    opt2 = torch.optim.SGD(ref.parameters(), lr=0.0)
+    outs = []
+    for mdl, o in ((model, opt), (ref, opt2)):
+        seed_train()
+        outs.append(ic.train_step(mdl, o, tokens.to(DEV), ic.LossWeights(), torch.device(DEV)))
+    for k in KEYS:
+        assert outs[0][k] == outs[1][k], k
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert (p.grad is None) == (q.grad is None) and (p.grad is None or torch.equal(p.grad, q.grad)), n
 
 
 def test_early_halt_engine_equals_general_path(monkeypatch):
