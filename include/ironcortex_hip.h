@@ -386,7 +386,17 @@ typedef struct ic_heads_args {
                                input for the NEXT outer iteration should this step win (model.py:344-349) */
 } ic_heads_args;
 int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
-/* The same, with up to two GEMVs riding in its two launches (either may be NULL):
+/* ic_heads_fwd for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs,
+ * outputs and results (bit for bit) as ic_heads_fwd, but a->z, a->per_region and a->gsq are IGNORED
+ * (may be NULL): those inter-launch buffers live in a static device array of
+ * IC_HEADS_STATIC_FLOATS floats (4 MiB per GPU the library runs on, held until the process ends).
+ * Returns IC_EINVAL when S*(Kf + Kf*V) + S*R*V + S*2R (each term padded to 64) exceeds it.
+ * Calls no hipMalloc / hipFree / event creation (its launches are never profiled by ic_prof_*).
+ * All calls on one GPU share the array: calls that overlap on one GPU (different streams) race. */
+enum { IC_HEADS_STATIC_FLOATS = 1 << 20 };
+int ic_heads_fwd_static(const ic_heads_args* a, ic_stream_t stream);
+/* The same as ic_heads_fwd, with up to two GEMVs riding in its two launches (either may be NULL):
  *   g_mean  takes the mean of each stream's active rows of H as its d-column input (the first planner
  *           layer, heads.py:57 on model.py:344-349; nbatch must equal S) and rides in the FIRST launch;
  *           bit-identical to ws_mean followed by ic_gemv_chain(g_mean, 1);

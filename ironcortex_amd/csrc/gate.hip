@@ -28,7 +28,7 @@ extern "C" int ic_device_check(char* name, int cap) {
     ic_set_error("ic_device_check: built for gfx950, device is %s", prop.gcnArchName);
     return IC_EDEVICE;
   }
-  return IC_OK;
+  return ic_heads_static_setup(nullptr);  // per-device address of ic_heads_fwd_static's scratch array
 }
 
 namespace {

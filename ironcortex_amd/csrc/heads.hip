@@ -3,6 +3,8 @@
 // (planner / critic) and :425-438 (verifier energy + branch score) when no gradient is needed.
 // All of it is latency-bound vector work (<= 2.5 MB of weights per step): the kernels are
 // written for few launches and coalesced row reads, not for bandwidth.
+#include <mutex>
+
 #include "ic_common.h"
 #include "ic_kwta.h"
 
@@ -747,9 +749,12 @@ extern "C" int ic_verify_score(const ic_gemv_desc* descs, int32_t n, const float
   return IC_OK;
 }
 
-static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_gemv_desc* g, ic_stream_t stream);
+static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_gemv_desc* g, ic_stream_t stream,
+                     bool timed);
 
-extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) { return heads_fwd(a, nullptr, nullptr, stream); }
+extern "C" int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream) {
+  return heads_fwd(a, nullptr, nullptr, stream, true);
+}
 
 extern "C" int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g_mean, const ic_gemv_desc* g_next,
                                  ic_stream_t stream) {
@@ -769,10 +774,19 @@ extern "C" int ic_heads_gemv_fwd(const ic_heads_args* a, const ic_gemv_desc* g_m
     IC_REQUIRE(g_next->n0 + g_next->n1 + g_next->n2 <= 1024, "ic_heads_gemv_fwd: %d input columns (need <= 1024)",
                g_next->n0 + g_next->n1 + g_next->n2);
   }
-  return heads_fwd(a, g_mean, g_next, stream);
+  return heads_fwd(a, g_mean, g_next, stream, true);
 }
 
-static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_gemv_desc* g, ic_stream_t stream) {
+// timed = false: the launches are never bracketed by profiling events (ic_prof_begin may create
+// events, i.e. allocate), for the entry point that must not allocate.
+#define IC_MAYBE_TIMED(timed, kid, st, ...) \
+  do {                                      \
+    if (timed) IC_TIMED(kid, st, __VA_ARGS__); \
+    else { __VA_ARGS__; }                   \
+  } while (0)
+
+static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_gemv_desc* g, ic_stream_t stream,
+                     bool timed) {
   IC_REQUIRE(a != nullptr, "ic_heads_fwd: NULL args");
   IC_REQUIRE(a->R > 0 && a->V > 0 && a->Kf > 0 && a->Kf <= 16 && a->n_slots >= 0,
              "ic_heads_fwd: R=%d V=%d Kf=%d n_slots=%d", a->R, a->V, a->Kf, a->n_slots);
@@ -791,7 +805,7 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_ge
                    ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0) + n_g;
   ic_gemv_desc g_none = {};
   IC_DISPATCH_DCH(a->d, {
-    IC_TIMED(IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, S), dim3(256), 0, st, *a, gm ? *gm : g_none, n_g));
+    IC_MAYBE_TIMED(timed, IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, S), dim3(256), 0, st, *a, gm ? *gm : g_none, n_g));
   });
   if (g) {
     const int cols = g->n0 + g->n1 + g->n2, nb = g->nbatch > 1 ? g->nbatch : 1;
@@ -800,10 +814,70 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_ge
     else if (cols <= 512) IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_combine_gemv<8>, grid, dim3(256), 0, st, *a, *g, S));
     else IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_combine_gemv<16>, grid, dim3(256), 0, st, *a, *g, S));
   } else {
-    IC_TIMED(IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(S), dim3(256), 0, st, *a));
+    IC_MAYBE_TIMED(timed, IC_KID_logits_combine, st, hipLaunchKernelGGL(k_logits_combine, dim3(S), dim3(256), 0, st, *a));
   }
   IC_LAUNCH_CHECK("ic_heads_fwd");
   return IC_OK;
+}
+
+// ------------------------------------------------------------------ ic_heads_fwd without any allocation
+// The three inter-launch buffers of ic_heads_fwd (z, per_region, gsq: written by its first launch,
+// read by its second) live in a file-scope device array instead of caller-provided memory.  Each
+// GPU holds its own copy of the array at its own address: the address is looked up once per device
+// (hipGetSymbolAddress with that device current) and only that pointer is ever handed to kernels.
+// Nothing in the array has to start at zero: every word the second launch reads is written by the
+// first launch of the same call.  Calls that overlap on one GPU (two streams) share the array and race.
+static __device__ __align__(256) float scratch[IC_HEADS_STATIC_FLOATS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+}  // namespace
+
+// Resolves the scratch array's address on the CURRENT device (idempotent).  Called from
+// ic_device_check() -- the library's set-up call -- and, failing that, from the entry point's first
+// call on a device.
+__attribute__((visibility("hidden"))) int ic_heads_static_setup(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    ic_set_error("ic_heads_fwd_static: no current HIP device (or device index >= %d)", kMaxDevices);
+    return IC_EDEVICE;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      ic_set_error("ic_heads_fwd_static: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+      return IC_EDEVICE;
+    }
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  if (out) *out = g_scratch_ptr[dev];
+  return IC_OK;
+}
+
+extern "C" int ic_heads_fwd_static(const ic_heads_args* a, ic_stream_t stream) {
+  IC_REQUIRE(a != nullptr, "ic_heads_fwd_static: NULL args");
+  IC_REQUIRE(a->R > 0 && a->V > 0 && a->Kf > 0, "ic_heads_fwd_static: R=%d V=%d Kf=%d", a->R, a->V, a->Kf);
+  const size_t S = a->S > 1 ? (size_t)a->S : 1;
+  // per-stream blocks, each padded to 64 floats (256 bytes)
+  auto pad = [](size_t n) { return (n + 63) / 64 * 64; };
+  const size_t nz = pad(S * ((size_t)a->Kf + (size_t)a->Kf * a->V)), npr = pad(S * (size_t)a->R * a->V),
+               ng = pad(S * 2 * (size_t)a->R);
+  IC_REQUIRE(nz + npr + ng <= (size_t)IC_HEADS_STATIC_FLOATS,
+             "ic_heads_fwd_static: S=%zu R=%d V=%d Kf=%d needs %zu scratch floats, the static buffer holds %d "
+             "(use ic_heads_fwd with caller-provided z / per_region / gsq)",
+             S, a->R, a->V, a->Kf, nz + npr + ng, IC_HEADS_STATIC_FLOATS);
+  float* base = nullptr;
+  const int rc = ic_heads_static_setup(&base);
+  if (rc) return rc;
+  ic_heads_args b = *a;
+  b.z = base;
+  b.per_region = base + nz;
+  b.gsq = base + nz + npr;
+  return heads_fwd(&b, nullptr, nullptr, stream, /*timed=*/false);
 }
 
 extern "C" int ic_branch_score(const float* stats, const float* energy, float* score, ic_stream_t stream) {

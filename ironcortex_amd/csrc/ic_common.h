@@ -205,6 +205,10 @@ void ic_prof_end(int kid, hipStream_t st);
 
 static inline int ic_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// library-internal (heads.hip): looks up, once per device, the address of the static scratch array of
+// ic_heads_fwd_static on the current device
+__attribute__((visibility("hidden"))) int ic_heads_static_setup(float** out);
+
 // library-internal: gate + router edge launch of ic_front_fwd, with or without the combine launch
 __attribute__((visibility("hidden"))) int ic_front_launch(const ic_gate_args* g, const ic_router_args* a,
                                                           ic_stream_t stream, bool combine);
