@@ -40,6 +40,13 @@ def check(tag: str, what: str, a, b, tol: float, floor: float = 0.0):
     return e
 
 
+def note(tag: str, cls: str, err: float, what: str = ""):
+    """Remember an error measured by the caller's own metric."""
+    w = _worst.setdefault(tag, {})
+    if err >= w.get(cls, (-1.0, ""))[0]:
+        w[cls] = (err, what)
+
+
 def flush(tag: str):
     w = _worst.pop(tag, None)
     if not w:

@@ -1,0 +1,214 @@
+"""GPU parity of the kernel variants the roofline sweep times (BASELINE configs[2]; VERDICT r1
+items 2 / weak 3-4): region phase and router at R in {64, 512}, d = 256, sparse top-k style masks,
+S in {1, 8} streams, rows_fwd in {library default, 16, 32}, per-edge routing with and without
+precision weighting -- forward AND backward, each against the CPU oracle (oracle/hotpath.py, pinned
+to the reference by tests/test_oracle_vs_reference.py), never against another HIP launch.
+
+reference: region.py:168-249 (cell step), model.py:271-294 (region loop), gate.py:251-335 (router).
+Tolerances: every [.., d] row is compared relative to that row's own largest reference magnitude
+(an elementwise rtol/atol pair misreads rows whose entries span e^-3..e^+3, as exp(k)-weighted
+state rows do at d = 256): activations and new state 2e-5.  Gradients: relative to the largest
+magnitude of the same [R,d] stream block / d x d matrix, 1e-4 (a row of dW = g_i * x inherits the
+relative error of a g_i that is itself a cancelling sum, so single rows say nothing).  KWTA winners and the
+set of parameters that receive a gradient must be identical.  Observed errors are logged
+(tests/parity_log.py)."""
+import pytest
+import torch
+
+from tests import parity_log as PL
+from tests.golden import inputs as gi
+from tests.test_hip_parity import build_bank
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+D = 256
+
+
+def row_err(a, b) -> float:
+    """max over rows of max|a - b| / max|b| of that row (rows that are zero in both are skipped)."""
+    a = a.detach().double().cpu().reshape(-1, a.shape[-1]) if a.dim() > 1 else a.detach().double().cpu().reshape(1, -1)
+    b = b.detach().double().cpu().reshape(a.shape)
+    scale = b.abs().amax(1)
+    diff = (a - b).abs().amax(1)
+    live = (scale > 0) | (diff > 0)
+    if not bool(live.any()):
+        return 0.0
+    return float((diff[live] / scale[live].clamp_min(1e-30)).max())
+
+
+_TAG = [""]
+
+
+def block_err(a, b) -> float:
+    """max over leading-index blocks of max|a - b| / max|b| of that block."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if a.dim() >= 3:
+        a, b = a.reshape(a.shape[0], -1), b.reshape(a.shape[0], -1)
+    else:
+        a, b = a.reshape(1, -1), b.reshape(1, -1)
+    return row_err(a, b)
+
+
+def close(a, b, what="", tol=2e-5, err=None):
+    e = (err or row_err)(a, b)
+    PL.note(_TAG[0], what.split("[")[0], e, what)
+    assert e <= tol, f"{_TAG[0]} {what}: row-relative error {e:.3e} > {tol:.0e}"
+
+
+def gclose(a, b, what=""):
+    if b is None:  # the oracle saw no use of this input (e.g. no sensor/motor region active)
+        assert a is None or float(a.abs().max()) == 0.0, what
+        return
+    close(a, b, what, tol=1e-4, err=block_err)
+
+
+class _PerRegion:
+    """P["W"][r, j] for the oracle with one autograd leaf per ACTIVE region (indexing one [R,4,d,d]
+    leaf would zero-fill a 0.5 GB gradient per use at R = 512)."""
+
+    def __init__(self, W, active):
+        self.leaf = {int(r): W[int(r)].clone().requires_grad_(True) for r in active}
+
+    def __getitem__(self, idx):
+        r, j = idx
+        return self.leaf[int(r)][j]
+
+
+def sparse_mask(seed, S, R, k):
+    """Each stream: the first k entries of a seeded permutation of the regions."""
+    g = torch.Generator().manual_seed(seed)
+    mask = torch.zeros(S, R, dtype=torch.bool)
+    for s in range(S):
+        mask[s, torch.randperm(R, generator=g)[:k]] = True
+    return mask
+
+
+@pytest.mark.parametrize("R,S,k", [(64, 1, 8), (64, 8, 8), (512, 1, 32), (512, 8, 32)])
+def test_region_phase_sweep_variants_vs_oracle(R, S, k, monkeypatch):
+    from ironcortex_amd.hip import ops
+    from oracle import hotpath as O
+    seed = 7000 + R + S
+    bank, cells, P = build_bank(R, D, False, False, "scalar", seed)
+    st = {"num": gi.det(seed + 10, S, R, D, kind="rand"), "den": gi.det(seed + 11, S, R, D, kind="rand", shift=0.5),
+          "var": torch.zeros(S, R, D), "pred": gi.det(seed + 13, S, R, D, scale=0.1), "radius": torch.zeros(S, R),
+          "radius_var": torch.zeros(S, R), "surprise": torch.zeros(S, R),
+          "dt": (gi.det(seed + 17, S, R, kind="rand") * 8).to(torch.int32)}
+    M, sensor = gi.det(seed + 18, S, R, D), gi.det(seed + 19, S, D)
+    mask = sparse_mask(seed + 20, S, R, k)
+    nin = gi.det(seed + 21, D, scale=0.1, shift=1.0)
+    gH, gnum, gden, gpred = (gi.det(seed + 40 + i, S, R, D, scale=sc) for i, sc in enumerate((1.0, 0.3, 0.3, 0.3)))
+    active = mask.any(0).nonzero().flatten().tolist()
+    # ---- oracle (CPU autograd)
+    Wl = _PerRegion(P["W"], active)
+    Pc = {k_: v.clone().requires_grad_(True) for k_, v in P.items() if k_ != "W"}
+    Pc["W"], Pc["W_time"] = Wl, O.time_freqs(D)
+    stc = {k_: (v.clone().requires_grad_(True) if k_ in ("num", "den", "pred") else v.clone()) for k_, v in st.items()}
+    Mc, sc_, ninc = M.clone().requires_grad_(True), sensor.clone().requires_grad_(True), nin.clone().requires_grad_(True)
+    Hc, newc = O.region_phase(Pc, stc, Mc, sc_, mask, 0.5, norm_in_w=ninc, sensor_idx=0, motor_idx=R - 1, kwta_k=D // 8)
+    ((Hc * gH).sum() + (newc["num"] * gnum).sum() + (newc["den"] * gden).sum() + (newc["pred"] * gpred).sum()).backward()
+    # ---- HIP, once per forward row-slice variant (0 = the library's own choice for this R)
+    for rows in (0, 16, 32):
+        monkeypatch.setattr(ops, "ROWS_FWD", rows)
+        bank.reset_state(torch.device(DEV), S)
+        leaves = {k_: st[k_].clone().to(DEV).requires_grad_(True) for k_ in ("num", "den", "pred")}
+        for k_, v in leaves.items():
+            setattr(bank, k_, v * 1.0)
+        bank.dt = st["dt"].to(DEV)
+        Mg, sg, ning = M.to(DEV).requires_grad_(True), sensor.to(DEV).requires_grad_(True), nin.to(DEV).requires_grad_(True)
+        Hg = bank.phase(Mg, sg, ning, mask.to(torch.uint8).to(DEV), 0.5)
+        ((Hg * gH.to(DEV)).sum() + (bank.num * gnum.to(DEV)).sum() + (bank.den * gden.to(DEV)).sum()
+         + (bank.pred * gpred.to(DEV)).sum()).backward()
+        tag = _TAG[0] = f"sweep-region/R{R}/S{S}/rows{rows}"
+        assert torch.equal((Hg != 0).cpu(), Hc != 0), "KWTA winners differ"
+        close(Hg, Hc, what="H")
+        for k_ in ("num", "den", "pred"):
+            close(getattr(bank, k_), newc[k_], what=k_)
+        assert torch.equal(bank.dt.cpu(), newc["dt"])
+        gclose(Mg.grad, Mc.grad, what="g.M"); gclose(sg.grad, sc_.grad, what="g.sensor"); gclose(ning.grad, ninc.grad, what="g.norm_in")
+        for k_ in ("num", "den", "pred"):
+            gclose(leaves[k_].grad, stc[k_].grad, what="g." + k_)
+        on = set(active)
+        for r, c in enumerate(cells):
+            if r not in on:
+                assert c.r_lin.weight.grad is None and c.norm.weight.grad is None  # untouched -> None (AdamW skip)
+                continue
+            gw = torch.stack([lin.weight.grad for lin in (c.r_lin, c.k_lin, c.v_lin, c.o_lin)])
+            gclose(gw, Wl.leaf[r].grad, what=f"g.W[{r}]")
+            gclose(c.norm.weight.grad, Pc["norm_w"].grad[r], what="g.norm_w")
+            gclose(c.raw_decay.grad, Pc["raw_decay"].grad[r], what="g.raw_decay")
+        for c in cells:
+            for p in c.parameters():
+                p.grad = None
+        PL.flush(tag)
+
+
+@pytest.mark.parametrize("R,S,k", [(64, 1, 8), (64, 8, 8), (512, 1, 32), (512, 8, 32)])
+@pytest.mark.parametrize("prec", [False, True], ids=["plain", "precision"])
+def test_router_sweep_sizes_vs_oracle(R, S, k, prec):
+    """per-edge routing at d = 256 (k_router_fwd_ms / k_router_edge_fwd + combine, and their
+    backward kernels) against the per-stream oracle."""
+    from ironcortex_amd.gate import Router
+    from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
+    from oracle import hotpath as O
+    seed = 7500 + R + S
+    nb = hex_neighbors(R)
+    coords = hex_axial_coords(R)
+    router = Router(nb, D, R, enable_precision_routed_messages=prec).to(DEV)
+    E = router.E
+    mask = sparse_mask(seed, S, R, k)
+    src = router.src_idx.cpu()
+    e_act = mask[:, src].any(0).nonzero().flatten().tolist()          # edges with an active sender in some stream
+    W_edge = gi.det(seed + 1, E, D, D, kind="xavier")
+    key_W = gi.det(seed + 2, E, D, D, kind="xavier") if prec else None
+    query_W = gi.det(seed + 3, R, D, D, kind="xavier") if prec else None
+    raw_P = gi.det(seed + 4, E, D, scale=0.3, shift=-2.0)
+    t = dict(W_reg=gi.det(seed + 5, 8, 2), beta_cos=gi.det(seed + 6, 8, scale=0.3), beta_sin=gi.det(seed + 7, 8, scale=0.3))
+    with torch.no_grad():  # parameters are views of the router's arenas: fill the stacked views directly
+        router._flat.stacked("W").copy_(W_edge)
+        if prec:
+            router._flat.stacked("key_W").copy_(key_W)
+            router._flat.stacked("query_W").copy_(query_W)
+            router._flat.stacked("raw_P").copy_(raw_P)
+        router.W_reg.copy_(t["W_reg"]); router.beta_cos.copy_(t["beta_cos"]); router.beta_sin.copy_(t["beta_sin"])
+    H = gi.det(seed + 8, S, R, D) * mask.unsqueeze(-1)  # inactive regions carry zero states, as in the loop
+    gM = gi.det(seed + 9, S, R, D)
+    # ---- HIP
+    Hg = H.to(DEV).requires_grad_(True)
+    M = router.route(Hg, mask.to(torch.uint8).to(DEV), coords.to(DEV))
+    (M * gM.to(DEV)).sum().backward()
+    # ---- oracle: one autograd leaf per touched matrix
+    leaf = lambda x: x.clone().requires_grad_(True)
+    on = set(e_act)
+    P = {"W_edge": [leaf(W_edge[e]) if e in on else W_edge[e] for e in range(E)], "W_reg": t["W_reg"],
+         "beta_cos": leaf(t["beta_cos"]), "beta_sin": leaf(t["beta_sin"])}
+    if prec:
+        P["key_W"] = [leaf(key_W[e]) if e in on else key_W[e] for e in range(E)]
+        P["raw_P"] = [leaf(raw_P[e]) if e in on else raw_P[e] for e in range(E)]
+        P["query_W"] = [leaf(query_W[r]) for r in range(R)]
+    Hc = H.clone().requires_grad_(True)
+    Mc = torch.stack([O.router_messages(P, Hc[s], mask[s], coords, nb, precision=prec)[0] for s in range(S)])
+    (Mc * gM).sum().backward()
+    tag = _TAG[0] = f"sweep-router/R{R}/S{S}/{'precision' if prec else 'plain'}"
+    close(M, Mc, what="M")
+    gclose(Hg.grad, Hc.grad, what="g.H")
+    gclose(router.beta_cos.grad, P["beta_cos"].grad, what="g.beta_cos")
+    gclose(router.beta_sin.grad, P["beta_sin"].grad, what="g.beta_sin")
+    for e, key in enumerate(router.edge_keys):
+        g = router.W_edge[key].weight.grad
+        assert (g is not None) == (e in on), key  # inactive senders leave their edge weights without a gradient
+        if g is not None:
+            gclose(g, P["W_edge"][e].grad, what=f"g.W_edge[{key}]")
+    if prec:
+        # (an edge that dominates its destination's softmax has d loss / d log-weight ~ 0 by cancellation,
+        # and raw_P's gradient is proportional to it: compared against the largest raw_P gradient of the call)
+        keys = [router.edge_keys[e] for e in e_act]
+        # and the key / query matrices' to d loss / d score, which cancels the same way)
+        close(torch.stack([router.raw_P_edge[k_].grad for k_ in keys]).reshape(1, -1),
+              torch.stack([P["raw_P"][e].grad for e in e_act]).reshape(1, -1), what="g.rawP", tol=1e-4)
+        close(torch.stack([router.key_lin[k_].weight.grad for k_ in keys]).reshape(1, -1),
+              torch.stack([P["key_W"][e].grad for e in e_act]).reshape(1, -1), what="g.key", tol=1e-4)
+        zq = torch.zeros(D, D)
+        close(torch.stack([router.query_lin[r].weight.grad.cpu() for r in range(R)]).reshape(1, -1),
+              torch.stack([P["query_W"][r].grad if P["query_W"][r].grad is not None else zq for r in range(R)]).reshape(1, -1),
+              what="g.query", tol=1e-4)
+    PL.flush(tag)
