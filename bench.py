@@ -54,36 +54,56 @@ WORKLOAD = {"10m": "train_tiny_shakespeare_10m.py config (R=10,d=256,all flags o
 
 
 def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
-    """fp32 bytes one launch must move (u*16d^2-class weight bytes + n*vectors),
-    from per-launch averages counted on the device: n = (stream, region) pairs served, u = distinct
-    regions among them (a launch reads a region's weights once for all its streams)."""
-    afd = st["afd"]
-    dd = 4.0 * d * d
-    vec = 4.0 * d
+    """fp32 bytes one launch of a library kernel must move (u*16d^2-class
+    weight bytes + n*vectors), from per-launch averages counted on the device:
+      n_f / n_b  (stream, region) pairs served by a forward / backward region launch,
+      u_f / u_b  distinct regions among them (a launch reads a region's weights once for all its streams),
+      e          distinct active edges, ep  (stream, edge) pairs, q  destinations with an active in-edge,
+      S, R       streams and regions of the launch.
+    Kernels whose bytes follow from their shapes alone (the GEMV chains, the heads) are priced by the
+    library itself at launch time (ic_prof_bytes_read, see kernel_bytes()); 0.0 = no model."""
+    afd = st.get("afd", False)
+    dd, vec = 4.0 * d * d, 4.0 * d
+    S, R = st.get("S", 1), st.get("R", 0)
+    n_f, u_f, n_b, u_b = st.get("n_f", 0), st.get("u_f", 0), st.get("n_b", 0), st.get("u_b", 0)
+    e, ep, q, prec = st.get("e", 0), st.get("ep", st.get("e", 0)), st.get("q", 0), st.get("prec", False)
     table = {
-        "region_rkv": st["u_f"] * 3 * dd + st["n_f"] * (10 + (5 if afd else 0)) * vec,
-        "region_out": st["u_f"] * dd + st["n_f"] * 3 * vec,
-        "region_rkv_bwd": st["u_b"] * 3 * dd + st["n_b"] * (16 + (6 if afd else 0)) * vec,
-        "region_out_bwd": st["u_b"] * dd + st["n_b"] * 4 * vec,
+        # forward region phase
+        "region_pro": n_f * 6 * vec,                                    # M, pred, norm_w (+sensor) in; u1, x out
+        "region_rkv": u_f * 3 * dd + n_f * (10 + (5 if afd else 0)) * vec,
+        "region_out": u_f * dd + n_f * 3 * vec,
+        # active rows: hpre in, H / gate / pred out; idle rows: M, pred, num, den in, H, pred, num, den out (state is functional)
+        "region_fin": n_f * 4 * vec + (S * R - n_f) * 8 * vec + S * R * 9,
+        # backward region phase (weights re-read; dW deferred to wgrad_region)
+        "region_out_bwd": u_b * dd + n_b * 4 * vec,
+        "region_rkv_bwd": u_b * 3 * dd + n_b * (16 + (6 if afd else 0)) * vec,
+        "region_pro_bwd": n_b * 10 * vec,
+        "region_fin_bwd": n_b * 4 * vec,
+        "wgrad_region": u_b * 4 * dd * 2 + n_b * 6 * vec,               # dW read-modify-write once per touched region + tape
+        # router
+        "router_fwd": e * (dd + vec) + R * S * vec,
+        "router_edge_fwd": e * (2 * dd + 3 * vec) + q * (dd + 2 * vec),
+        "router_combine": ep * 3 * vec + S * R * vec,
+        "router_comb_bwd": ep * 5 * vec + S * R * 2 * vec,
+        "router_mat_bwd": e * ((2 if prec else 1) * dd + 4 * vec) + (q * (dd + 2 * vec) if prec else 0),
+        "router_gather_bwd": ep * vec + S * R * vec,
+        "wgrad_edge": e * dd * 2 + ep * 2 * vec,
+        # gate / primitives
+        "gate_scores": S * R * vec, "gate_select": S * R * (vec if R <= 64 else 8.0),
+        "kwta_rows": st.get("rows", 0) * 3 * vec, "goodness_fwd": st.get("rows", 0) * vec, "goodness_bwd": st.get("rows", 0) * 2 * vec,
+        "hebbian": st.get("e_upd", 0) * dd * 2,
     }
     if st.get("routed"):  # ic_loop_step_fwd: the router's combine rides in the r/k/v kernel (per launch: e_f active
         # incoming edges -> message, key, precision rows; q_f destinations -> state and query rows in, M row out)
         table["region_rkv"] += (3 * st["e_f"] + 3 * st["q_f"]) * vec
-    if "e" in st:  # the kernel sweep also prices the router: e = distinct active edges, q = destinations
-        e, q, R, prec = st["e"], st.get("q", 0), st["R"], st.get("prec", False)
-        table.update({
-            "router_fwd": e * (dd + vec) + R * vec,
-            "router_edge_fwd": e * (2 * dd + 3 * vec) + q * (dd + 2 * vec),
-            "router_mat_bwd": e * ((2 if prec else 1) * dd + 4 * vec) + (q * (dd + 2 * vec) if prec else 0),
-        })
     return table.get(kernel, 0.0)
 
 
 def pmc_traffic(kernel: str, cfg_name: str):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r01_pmc_traffic.json; PMC collection serialises kernels, so it is a
+    command (profiles/r02_pmc_traffic.json; PMC collection serialises kernels, so it is a
     separate run, never the timed one).  None when no measurement is on file for the config."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if cfg_name != "10m" or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -159,7 +179,7 @@ def main():
     model = ic.CortexReasoner(ic.hex_neighbors(R), ic.hex_axial_coords(R), {"sensor": 0, "motor": R - 1}, cfg).to(dev)
     if dp is not None:
         dp.broadcast_module(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)  # the reference's optimizer (train_tiny_shakespeare.py:86)
     n_params = sum(p.numel() for p in model.parameters())
     gen = torch.Generator().manual_seed(1234 + rank)
     B, T = args.batch, args.seq
@@ -174,7 +194,7 @@ def main():
             torch.cuda.synchronize()
 
     timing = not args.no_kernel_timing
-    survey = {}
+    survey, survey_bytes = {}, {}
     for w in range(args.warmup):
         last = timing and w == args.warmup - 1
         if last:  # untimed survey step: every library kernel bracketed by events, to find the dominant one
@@ -182,22 +202,25 @@ def main():
             hip.prof_select("")
             hip.prof_enable(True)
             hip.prof_read()
+            hip.prof_bytes_read()
         ic.train_step(model, opt, tokens, lw, dev, dp=dp)
         if last:
             survey = hip.prof_read()
+            survey_bytes = hip.prof_bytes_read()
             hip.prof_enable(False)
     model.count_units(True)
     dominant = None
     if timing:
-        unit = dict(u_f=1, n_f=1, u_b=1, n_b=1, afd=0)
-        cand = [k for k in survey if algorithmic_bytes(k, cfg.d, unit) > 0]
-        if cand:
-            dominant = max(cand, key=lambda k: survey[k][1])
+        # the dominant kernel = the largest summed duration among ALL library kernels (every one has a byte model:
+        # algorithmic_bytes() or the library's own launch-time count)
+        if survey:
+            dominant = max(survey, key=lambda k: survey[k][1])
         # timed region: only the dominant kernel carries events (two event records per launch would
         # otherwise cost more than most of these kernels run and distort `value`)
         hip.prof_select(dominant or "", stride=PROF_STRIDE)
         hip.prof_enable(True)
         hip.prof_read()
+        hip.prof_bytes_read()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -205,6 +228,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     prof = hip.prof_read() if timing else {}
+    lib_bytes = hip.prof_bytes_read() if timing else {}
     hip.prof_enable(False)
     hip.prof_select("")
     units = model.read_units()
@@ -228,35 +252,58 @@ def main():
             "loss_total": metrics["total"],
         }
         roof = None
-        if prof:
-            lib_ms = sum(ms for _, ms in survey.values()) if survey else sum(ms for _, ms in prof.values())
-            name = dominant or max((k for k in prof if algorithmic_bytes(k, cfg.d, dict(u_f=1, n_f=1, u_b=1, n_b=1, afd=0)) > 0),
-                                   key=lambda k: prof[k][1])
-            launches, ms = prof[name]
+        if prof and dominant:
+            nb = 1 if cfg.train_deterministic_inner_loop else max(1, cfg.B_br)
             lf, lb = max(1.0, units["fwd_region_launches"]), max(1.0, units["bwd_region_launches"])
-            st = dict(n_f=units["region_steps"] / lf, u_f=units["fwd_unique_regions"] / lf,
-                      n_b=units["bwd_pairs"] / lb, u_b=units["bwd_unique_regions"] / lb,
-                      afd=cfg.enable_adaptive_filter_dynamics,
-                      routed=bool(cfg.enable_precision_routed_messages and cfg.d <= 256 and not cfg.train_deterministic_inner_loop
-                                  and cfg.B_br > 1 and os.environ.get("IC_FUSE_STEP", "1") != "0"),
-                      e_f=units["active_edges"] / lf, q_f=units["dst_regions"] / lf)
-            ab = algorithmic_bytes(name, cfg.d, st)
+            lrb = max(1.0, units["bwd_router_launches"])
+            prec = bool(cfg.enable_precision_routed_messages)
+            fwd = dict(S=nb, R=cfg.R, n_f=units["region_steps"] / lf, u_f=units["fwd_unique_regions"] / lf,
+                       e=units["active_edges"] / lf, ep=units["active_edges"] / lf, q=units["dst_regions"] / lf,
+                       afd=cfg.enable_adaptive_filter_dynamics, prec=prec,
+                       routed=bool(prec and cfg.d <= 256 and not cfg.train_deterministic_inner_loop
+                                   and cfg.B_br > 1 and os.environ.get("IC_FUSE_STEP", "1") != "0"),
+                       e_f=units["active_edges"] / lf, q_f=units["dst_regions"] / lf)
+            bwd = dict(S=2 * B, R=cfg.R, n_b=units["bwd_pairs"] / lb, u_b=units["bwd_unique_regions"] / lb,
+                       e=units["bwd_unique_edges"] / lrb, ep=units["bwd_edge_pairs"] / lrb, q=units["bwd_dst_regions"] / lrb,
+                       afd=cfg.enable_adaptive_filter_dynamics, prec=prec, rows=2 * B * cfg.R, e_upd=model.router.E)
+
+            def bytes_per_launch(name, libb):
+                """algorithmic bytes of one launch of `name`: the library's own count for shape-determined kernels
+                (+ the mask-dependent region-head rows of the heads kernel), else the unit model."""
+                if name in libb and libb[name][0]:
+                    ab = libb[name][1] / libb[name][0]
+                    if name == "token_rows":  # + one V x d head per active non-motor region of each stream
+                        ab += max(0.0, fwd["n_f"] - nb) * cfg.V * 4.0 * cfg.d
+                    return ab
+                st = bwd if (name.endswith("_bwd") or name.startswith("wgrad") or name in ("hebbian", "goodness_fwd", "goodness_bwd")) else fwd
+                return algorithmic_bytes(name, cfg.d, st)
+
+            launches, ms = prof[dominant]
+            ab = bytes_per_launch(dominant, lib_bytes)
             avg_s = ms / launches * 1e-3
             achieved = ab / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "k_" + name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, args.config), "launches": launches,
+            lib_ms = sum(ms_ for _, ms_ in survey.values())
+            roof = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant, args.config), "launches": launches,
                     "launch_sampling": f"HIP events on 1 launch in {PROF_STRIDE} over the timed region",
                     "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ab,
-                    "units_per_launch": ({"pairs": st["n_b"], "distinct_regions": st["u_b"]} if name.endswith("_bwd")
-                                         else {"pairs": st["n_f"], "distinct_regions": st["u_f"]}),
-                    "library_kernel_ms_per_step": lib_ms / (1 if survey else args.steps),
+                    "dominant_by": "largest summed duration among ALL library kernels in the survey step",
+                    "units_per_launch": {k: round(v, 3) for k, v in (bwd if dominant.endswith("_bwd") else fwd).items()
+                                         if isinstance(v, float)},
+                    "library_kernel_ms_per_step": lib_ms,
                     "note": "working set fits the 256 MB Infinity Cache; launches are latency-bound at this size "
                             "(see profiles/ for the R=64..512 kernel sweep)"}
-            src = survey or prof
-            out["kernels_ms_per_step"] = {k: round(v[1] / (1 if survey else args.steps), 4)
-                                          for k, v in sorted(src.items(), key=lambda kv: -kv[1][1])}
-            out["kernels_ms_per_step_source"] = ("HIP events on every library kernel during the last warm-up step"
-                                                 if survey else "HIP events over the timed region")
+            # every library kernel of the survey step, priced the same way
+            table = {}
+            for k, (n_, ms_) in sorted(survey.items(), key=lambda kv: -kv[1][1]):
+                abk = bytes_per_launch(k, survey_bytes)
+                us = ms_ / n_ * 1e3
+                table[k] = {"ms_per_step": round(ms_, 4), "launches_per_step": n_, "avg_us": round(us, 2),
+                            "alg_KB_per_launch": round(abk / 1e3, 1),
+                            "GBs": round(abk / (us * 1e-6) / 1e9, 1) if abk else None}
+            out["kernels"] = table
+            out["kernels_source"] = ("HIP events on every library kernel during the last warm-up step; algorithmic bytes "
+                                     "from bench.algorithmic_bytes x device-counted units, or the library's launch-time count")
         out["roofline"] = roof
         # the same kernels where bytes, not launch latency, bound them (BASELINE configs[2], one point:
         # R=512, k=32, S=8 streams, d=256, forward): HIP events on every launch, ~2 s

@@ -442,6 +442,11 @@ int ic_prof_stride(int n);
 int ic_prof_kernel_count(void);
 const char* ic_prof_kernel_name(int kid);
 int ic_prof_read(int kid, int64_t* launches, double* total_ms);
+/* Launches and summed ALGORITHMIC bytes since the previous read, for the kernels whose traffic follows
+ * from their shapes alone (GEMV chains: rows x cols weights + vectors; heads; gate), counted on the host
+ * at launch time while profiling is enabled.  Mask-gathered kernels are priced by the caller from
+ * device-side unit counts (bench.py). */
+int ic_prof_bytes_read(int kid, int64_t* launches, double* bytes);
 
 #ifdef __cplusplus
 }

@@ -661,6 +661,12 @@ __global__ __launch_bounds__(256) void k_steer_select(ic_steer_args a) {
 
 }  // namespace
 
+// weights once (the batches of a launch share them), input and output vectors per batch
+static double gemv_bytes(const ic_gemv_desc& g) {
+  const double cols = g.n0 + g.n1 + g.n2, nb = g.nbatch > 1 ? g.nbatch : 1;
+  return 4.0 * ((double)g.rows * cols + nb * (cols + g.rows) + (g.b ? g.rows : 0) + (g.ln_g ? 2 * cols : 0));
+}
+
 static int check_gemv(const ic_gemv_desc& g, int i, const char* who) {
   const int cols = g.n0 + g.n1 + g.n2;
   IC_REQUIRE(g.W && g.y && g.rows > 0, "%s[%d]: NULL W/y or rows=%d", who, i, g.rows);
@@ -691,6 +697,7 @@ static int run_chain(const ic_gemv_desc* descs, int n, const float* stats, float
     c.n = n;
     c.stats = stats;
     c.score = score;
+    IC_BYTES(IC_KID_gemv, bytes + [&] { double v = 0; for (int i = 0; i < n; ++i) v += 4.0 * (descs[i].rows + descs[i].n0 + descs[i].n1 + descs[i].n2); return v; }());
     IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_chain1, dim3(1), dim3(1024), 0, st, c));
     return IC_OK;
   }
@@ -698,6 +705,7 @@ static int run_chain(const ic_gemv_desc* descs, int n, const float* stats, float
     float* sc = (i == n - 1) ? score : nullptr;
     const int cols = descs[i].n0 + descs[i].n1 + descs[i].n2;
     const dim3 grid(ic_ceil_div(descs[i].rows, 8), descs[i].nbatch > 1 ? descs[i].nbatch : 1), blk(256);
+    IC_BYTES(IC_KID_gemv, gemv_bytes(descs[i]));
     if (cols <= 256) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<4>, grid, blk, 0, st, descs[i], stats, sc));
     else if (cols <= 512) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<8>, grid, blk, 0, st, descs[i], stats, sc));
     else if (cols <= 1024) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_reg<16>, grid, blk, 0, st, descs[i], stats, sc));
@@ -732,6 +740,7 @@ extern "C" int ic_gemv_multi(const ic_gemv_desc* descs, int32_t n, const float* 
   IC_REQUIRE(cols <= 1024, "ic_gemv_multi: %d input columns (need <= 1024)", cols);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(ic_ceil_div(rows, 8), nb, n), blk(256);
+  IC_BYTES(IC_KID_gemv, [&] { double v = 0; for (int i = 0; i < n; ++i) v += gemv_bytes(descs[i]); return v; }());
   if (cols <= 256) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_multi<4>, grid, blk, 0, st, m, stats, score));
   else if (cols <= 512) IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_multi<8>, grid, blk, 0, st, m, stats, score));
   else IC_TIMED(IC_KID_gemv, st, hipLaunchKernelGGL(k_gemv_multi<16>, grid, blk, 0, st, m, stats, score));
@@ -804,6 +813,13 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_ge
   const int nblk = ic_ceil_div(a->Kf + a->Kf * a->V, 8) + a->R * ic_ceil_div(a->V, 8) + ic_ceil_div(a->n_slots, 4) +
                    ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0) + n_g;
   ic_gemv_desc g_none = {};
+  if (timed) {
+    // shape-determined part: MFS gate + facets, the two state blocks (goodness terms), workspace rows, the riding
+    // GEMV; the region-head rows of the ACTIVE regions (V x d each) are added by the caller from its unit counts
+    IC_BYTES(IC_KID_token_rows, 4.0 * ((double)(a->Kf + a->Kf * a->V) * (a->d + 1) + (double)S * (2.0 * a->R + 3.0 * a->n_slots) * a->d) +
+                                    (gm ? gemv_bytes(*gm) : 0.0));
+    IC_BYTES(IC_KID_logits_combine, 4.0 * (double)S * (a->Kf + (double)a->Kf * a->V + (double)a->R * a->V + 4.0 * a->V) + (g ? gemv_bytes(*g) : 0.0));
+  }
   IC_DISPATCH_DCH(a->d, {
     IC_MAYBE_TIMED(timed, IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, S), dim3(256), 0, st, *a, gm ? *gm : g_none, n_g));
   });
@@ -896,6 +912,7 @@ extern "C" int ic_steer_select(const ic_steer_args* a, ic_stream_t stream) {
   for (int c = 0; c < a->n_cand; ++c)
     IC_REQUIRE(a->H_cand[c] && a->mask_cand[c], "ic_steer_select: NULL candidate %d", c);
   hipStream_t st = (hipStream_t)stream;
+  IC_BYTES(IC_KID_steer_select, 4.0 * (a->R + 2.0) * a->d + a->R);
   IC_TIMED(IC_KID_steer_select, st, hipLaunchKernelGGL(k_steer_select, dim3(1), dim3(256), 0, st, *a));
   IC_LAUNCH_CHECK("ic_steer_select");
   return IC_OK;

@@ -31,15 +31,34 @@ void ic_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- wave64 reductions (all lanes receive the result) ----
+// DPP data movement inside the VALU (quad permutes, row mirrors, row broadcasts) instead of six
+// ds_bpermute round trips through the LDS crossbar per reduction: the sum lands in lane 63 and is
+// read back as a scalar.  Summation order: pairs, quads, half rows, rows of 16, rows 0+1 / 2+3, total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ic_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += ic_dpp<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += ic_dpp<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += ic_dpp<0x141, 0xF>(v);  // row_half_mirror
+  v += ic_dpp<0x140, 0xF>(v);  // row_mirror: every lane of a row of 16 holds the row's sum
+  v += ic_dpp<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += ic_dpp<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, ic_dpp<0xB1, 0xF>(v));
+  v = fmaxf(v, ic_dpp<0x4E, 0xF>(v));
+  v = fmaxf(v, ic_dpp<0x141, 0xF>(v));
+  v = fmaxf(v, ic_dpp<0x140, 0xF>(v));
+  // (rows that a row broadcast does not write read back 0 from ic_dpp: combine through a select, not fmaxf(v, 0))
+  const float b15 = ic_dpp<0x142, 0xA>(v);
+  const int row = (threadIdx.x & 63) >> 4;
+  v = (row & 1) ? fmaxf(v, b15) : v;
+  const float b31 = ic_dpp<0x143, 0xC>(v);
+  v = (row >= 2) ? fmaxf(v, b31) : v;
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // torch.nn.functional.softplus (beta=1, threshold=20)
@@ -201,6 +220,13 @@ void ic_prof_end(int kid, hipStream_t st);
     if (t__) ic_prof_begin(kid, (hipStream_t)(st));             \
     __VA_ARGS__;                                                \
     if (t__) ic_prof_end(kid, (hipStream_t)(st));               \
+  } while (0)
+
+// shape-determined algorithmic bytes of a launch (see prof.hip); costs one predictable branch when off
+void ic_prof_count(int kid, double bytes);
+#define IC_BYTES(kid, ...)                                       \
+  do {                                                           \
+    if (g_ic_prof_on) ic_prof_count(kid, (double)(__VA_ARGS__)); \
   } while (0)
 
 static inline int ic_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -11,6 +11,16 @@ int g_ic_prof_only = -1;  // -1: every kernel; otherwise only this kernel id is 
 static int g_stride = 1;  // bracket 1 launch in g_stride (of the launches that qualify)
 static unsigned g_tick = 0;
 
+// Algorithmic bytes of the launches whose traffic follows from their shapes alone (GEMV chains, heads,
+// gate): counted per kernel id on the host at launch time while profiling is on, every launch
+// (independent of the event sampling), read back with ic_prof_bytes_read().
+static int64_t g_nlaunch[IC_KID_COUNT] = {};
+static double g_bytes[IC_KID_COUNT] = {};
+void ic_prof_count(int kid, double bytes) {
+  g_nlaunch[kid] += 1;
+  g_bytes[kid] += bytes;
+}
+
 bool ic_prof_sampled() { return g_stride <= 1 || (g_tick++ % (unsigned)g_stride) == 0; }
 
 namespace {
@@ -78,5 +88,14 @@ extern "C" int ic_prof_read(int kid, int64_t* launches, double* total_ms) {
   g_open[kid].clear();
   *launches = n;
   *total_ms = ms;
+  return IC_OK;
+}
+extern "C" int ic_prof_bytes_read(int kid, int64_t* launches, double* bytes) {
+  IC_REQUIRE(kid >= 0 && kid < IC_KID_COUNT && launches && bytes, "ic_prof_bytes_read: bad argument");
+  std::lock_guard<std::mutex> lk(g_mu);
+  *launches = g_nlaunch[kid];
+  *bytes = g_bytes[kid];
+  g_nlaunch[kid] = 0;
+  g_bytes[kid] = 0.0;
   return IC_OK;
 }

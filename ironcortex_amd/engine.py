@@ -1349,6 +1349,13 @@ class LoopEngine:
 
         if m._units is not None:
             m._units[5:8] += torch.stack([torch.tensor(float(K), device=dev), mk.sum().float(), mk.amax(0).sum().float()])
+            if E > 0:  # per router-backward launch (step t, all loops): active (stream, edge) pairs, distinct edges / destinations
+                allm = chunk.fields["mask"][base:base + V]                                        # [V,R] by slot
+                pm = allm[slot.clamp_min(0).reshape(-1)].view(S, K, R) * (slot >= 0)[:, :, None].to(_U8)
+                ea = pm[:, :, router.src_idx]                                                     # [S,K,E]
+                eany = ea.amax(0).float()                                                         # [K,E]
+                dany = torch.zeros(K, R, device=dev).index_add_(1, router.dst_idx, eany).gt(0)
+                m._units[8:12] += torch.stack([torch.tensor(float(sum(r_live)), device=dev), ea.sum().float(), eany.sum(), dany.sum().float()])
         self._pass["blocks"].append((Z, V, s0))
         self._pass.setdefault("keep", []).append((sens, best, in_slot if E > 0 else None, mk))
         return Z["gsens"].view(S, K * 2, d).sum(1)

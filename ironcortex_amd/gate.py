@@ -157,7 +157,7 @@ class Router(FastAttrs, nn.Module):
         self._tables_key = None
         self._geom = None
         self._coord = _coord or ops.GradCoordinator()
-        self._coord.register(self._flat.begin_pass, self._finish_pass)
+        self._coord.register_flagged(self._flat.begin_pass, self._launch_wgrad, self._publish)
         self._tape: Optional[ops.Tape] = None
         self._tape_S = 0
         self._anchor = None
@@ -250,10 +250,12 @@ class Router(FastAttrs, nn.Module):
     def _grad_sink(self, name: str, rows: torch.Tensor, widx: torch.Tensor) -> None:
         self._flat.stacked_grad(name).index_add_(0, widx, rows)
 
-    def _finish_pass(self) -> None:
+    def _launch_wgrad(self):
+        """End of a backward pass, phase 1: the deferred dW / dKey / dQuery launches; returns the device-side
+        touched flags [nW (+ nW + R with precision routing)] for the GradCoordinator's single host read."""
         tape = self._tape
         if tape is None or tape.pos == 0:
-            return
+            return None
         dev = self._flat.flat.device
         spec = ops.RouterSpec(self.R, self.d, self.E, self.nW, self.enable_precision_routed_messages)
         tables = self._tables
@@ -264,17 +266,21 @@ class Router(FastAttrs, nn.Module):
             tq = torch.zeros(self.R, dtype=torch.uint8, device=dev)
             ops.router_wgrad(tape, spec, tables, self._tape_S, 1, self._flat.stacked_grad("key_W"), tk)
             ops.router_wgrad(tape, spec, tables, self._tape_S, 2, self._flat.stacked_grad("query_W"), tq)
-            flags = torch.cat([tw, tk, tq]).bool().tolist()
-            tw_l, tk_l, tq_l = flags[: self.nW], flags[self.nW: 2 * self.nW], flags[2 * self.nW:]
+            tw = torch.cat([tw, tk, tq])
+        tape.reset()
+        return tw
+
+    def _publish(self, flags) -> None:
+        """Phase 2: .grad views for the touched matrices."""
+        tw_l = flags[: self.nW]
+        if self.enable_precision_routed_messages:
+            tk_l, tq_l = flags[self.nW: 2 * self.nW], flags[2 * self.nW:]
             if any(tw_l):  # the reference stacks the queries of ALL regions (gate.py:293): zero grads, not None
                 tq_l = [True] * self.R
             self._flat.publish("key_W", tk_l)
             self._flat.publish("raw_P", tk_l)
             self._flat.publish("query_W", tq_l)
-        else:
-            tw_l = tw.bool().tolist()
         self._flat.publish("W", tw_l)
-        tape.reset()
 
     def _get_tape(self, S: int, device) -> ops.Tape:
         if self._tape is None or self._tape_S != S:

@@ -167,6 +167,19 @@ def prof_select(name: str = "", stride: int = 1) -> None:
     check(l.ic_prof_select(ctypes.c_int(kid)), "ic_prof_select")
 
 
+def prof_bytes_read() -> dict:
+    """{kernel name: (launches, algorithmic bytes)} counted by the library since the previous read
+    (shape-determined kernels only: GEMV chains, heads, steer)."""
+    out = {}
+    l = lib()
+    for kid in range(l.ic_prof_kernel_count()):
+        n, b = ctypes.c_int64(0), ctypes.c_double(0.0)
+        check(l.ic_prof_bytes_read(ctypes.c_int(kid), ctypes.byref(n), ctypes.byref(b)), "ic_prof_bytes_read")
+        if n.value:
+            out[l.ic_prof_kernel_name(ctypes.c_int(kid)).decode()] = (n.value, b.value)
+    return out
+
+
 def prof_read() -> dict:
     """{kernel name: (launches, total_ms)} since the previous read (synchronises)."""
     out = {}

@@ -37,16 +37,33 @@ class GradCoordinator:
     """Runs the deferred weight-gradient launches once per backward pass.
 
     Function.backward calls begin(); the first call of a pass zeroes the gradient slices that
-    start from None and queues an end-of-pass callback on the autograd engine."""
+    start from None and queues an end-of-pass callback on the autograd engine.  At the end of the
+    pass every participant first LAUNCHES its deferred work and hands back its device-side
+    "touched" flags (which matrices received a gradient); all flags are then read in ONE host
+    sync and each participant publishes .grad views for its touched parameters (untouched ones
+    keep None: what AdamW must see to skip them as the reference does).
+
+    Data parallel (dp set by train_step for the duration of a step): the flags -- together with
+    the has-a-gradient flags of the parameters outside the arenas (extra_params) -- are OR-ed
+    across ranks in the same exchange, so that None-ness is identical on every rank without a
+    host read of its own; a parameter another rank has a gradient for gets a zero gradient here."""
 
     def __init__(self):
         self._pending = False
         self._begin: List[Callable[[], None]] = []
         self._finish: List[Callable[[], None]] = []
+        self._flagged: List[tuple] = []  # (launch() -> Optional[uint8 tensor], publish(list of bool))
+        self.dp = None
+        self.extra_params: Optional[Callable[[], list]] = None
 
     def register(self, begin: Callable[[], None], finish: Callable[[], None]) -> None:
         self._begin.append(begin)
         self._finish.append(finish)
+
+    def register_flagged(self, begin: Callable[[], None], launch: Callable[[], Optional[torch.Tensor]],
+                         publish: Callable[[list], None]) -> None:
+        self._begin.append(begin)
+        self._flagged.append((launch, publish))
 
     def begin(self) -> None:
         if self._pending:
@@ -58,8 +75,28 @@ class GradCoordinator:
 
     def _end(self) -> None:
         try:
+            flags = [launch() for launch, _ in self._flagged]
             for f in self._finish:
                 f()
+            extra = self.extra_params() if (self.dp is not None and self.extra_params is not None) else []
+            parts = [t.reshape(-1) for t in flags if t is not None]
+            if extra:
+                parts.append(torch.tensor([0 if p.grad is None else 1 for p in extra], dtype=torch.uint8,
+                                          device=extra[0].device))
+            if not parts:
+                return
+            allf = torch.cat(parts)
+            if self.dp is not None:
+                allf = self.dp.any_flags(allf)
+            host = allf.bool().tolist()  # the one host sync of the backward pass
+            off = 0
+            for (_, publish), t in zip(self._flagged, flags):
+                if t is not None:
+                    publish(host[off:off + t.numel()])
+                    off += t.numel()
+            for p, h in zip(extra, host[off:]):
+                if h and p.grad is None:
+                    p.grad = torch.zeros_like(p)
         finally:
             self._pending = False
 

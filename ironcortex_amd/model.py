@@ -111,20 +111,35 @@ class CortexReasoner(FastAttrs, nn.Module):
         self._heads_flat.reflat()
         return self
 
+    def grad_layout(self):
+        """(gradient arenas, parameters whose gradient lives outside them) for the data-parallel exchange:
+        the region bank's and the router's gradients are already flat buffers (ironcortex_amd/flat.py)."""
+        c = getattr(self, "_grad_layout", None)
+        n = sum(1 for _ in self.parameters())
+        if c is None or c[0] != n:
+            arenas = [self.bank.flat, self.router._flat]
+            inside = {id(p) for fp in arenas for plist in fp.groups.values() for p in plist}
+            extra = [p for p in self.parameters() if p.requires_grad and id(p) not in inside]
+            c = (n, arenas, extra)
+            object.__setattr__(self, "_grad_layout", c)
+        return c[1], c[2]
+
     def count_units(self, on: bool) -> None:
         """Count region steps / active edges on the device (no sync) for throughput reports."""
         dev = self.reg_coords.device
-        self._units = torch.zeros(8, device=dev) if on else None
+        self._units = torch.zeros(12, device=dev) if on else None
         self.counters["inner_steps"] = 0
 
     def read_units(self) -> Dict[str, float]:
         self.engine.flush_units()
-        u = self._units.tolist() if self._units is not None else [0.0] * 8
+        u = self._units.tolist() if self._units is not None else [0.0] * 12
         # region-phase launches and, per launch, the (stream, region) pairs served and the distinct
         # regions among them (their weights are read once per launch): forward / backward
         return {"inner_steps": self.counters["inner_steps"], "region_steps": u[0], "active_edges": u[1],
                 "dst_regions": u[2], "fwd_region_launches": u[3], "fwd_unique_regions": u[4],
-                "bwd_region_launches": u[5], "bwd_pairs": u[6], "bwd_unique_regions": u[7]}
+                "bwd_region_launches": u[5], "bwd_pairs": u[6], "bwd_unique_regions": u[7],
+                # router backward launches: (stream, edge) pairs, distinct edges, distinct destinations
+                "bwd_router_launches": u[8], "bwd_edge_pairs": u[9], "bwd_unique_edges": u[10], "bwd_dst_regions": u[11]}
 
     def detach_state(self) -> None:
         if hasattr(self, "work") and self.work.slots.requires_grad:

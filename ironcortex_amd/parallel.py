@@ -66,20 +66,44 @@ class DataParallel:
                 off += t.numel()
             torch._foreach_copy_(ts, views)
 
+    def any_flags(self, flags: torch.Tensor) -> torch.Tensor:
+        """Element-wise OR of a uint8 flag vector across ranks (GradCoordinator: which matrices / parameters
+        received a gradient on ANY rank), as one all-reduce; no host read here."""
+        out = flags.to(torch.int32).contiguous()
+        dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.group)
+        return out
+
     # ------------------------------------------------------------------ gradients
-    def sync_grads(self, module: torch.nn.Module) -> None:
-        params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
-        if not params:
+    def attach(self, model) -> None:
+        """Hook this exchange into the model's backward pass: the per-pass touched flags (and the
+        has-a-gradient flags of the parameters outside the arenas) are OR-ed across ranks inside the
+        GradCoordinator's single end-of-pass host read, so None-ness is rank-consistent before
+        sync_grads() runs and needs no host read of its own."""
+        coord = model._coord
+        coord.dp = self
+        coord.extra_params = lambda: model.grad_layout()[1]
+
+    @staticmethod
+    def detach(model) -> None:
+        model._coord.dp = None
+
+    def sync_grads(self, model) -> None:
+        """Average the gradients over ranks.  The hot-path gradients (region bank, router: > 90 % of the
+        bytes) are all-reduced IN PLACE in their flat arenas -- no packing, no copy back; the remaining
+        parameters (token mixer, heads, norms: a few MB) go through one packed bucket per bucket_mb.
+        Needs attach(model) before the backward pass (train_step does both)."""
+        if hasattr(model, "grad_layout"):
+            arenas, extra = model.grad_layout()
+            for fp in arenas:
+                if fp.gflat is not None and fp.gflat.numel() > 0:
+                    dist.all_reduce(fp.gflat, op=dist.ReduceOp.SUM, group=self.group)
+                    fp.gflat.div_(self.world)
+            live = [p for p in extra if p.grad is not None]  # rank-consistent (GradCoordinator._end)
+            self._reduce_packed(live)
             return
-        dev = params[0].device
-        have = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=dev)
-        dist.all_reduce(have, op=dist.ReduceOp.MAX, group=self.group)
-        have_l = have.tolist()
-        live = [p for p, h in zip(params, have_l) if h]
-        for p in live:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        # pack into buckets, one all-reduce per bucket
+        self._sync_grads_generic(model)
+
+    def _reduce_packed(self, live: List[torch.nn.Parameter]) -> None:
         i = 0
         while i < len(live):
             j, n = i, 0
@@ -96,3 +120,18 @@ class DataParallel:
                 off += k
             torch._foreach_copy_([p.grad for p in live[i:j]], views)  # one multi-tensor launch
             i = j
+
+    def _sync_grads_generic(self, module: torch.nn.Module) -> None:
+        """Any nn.Module (no arenas): None-ness made consistent with one flag exchange (a host read)."""
+        params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            return
+        dev = params[0].device
+        have = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MAX, group=self.group)
+        have_l = have.tolist()
+        live = [p for p, h in zip(params, have_l) if h]
+        for p in live:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        self._reduce_packed(live)

@@ -67,7 +67,7 @@ class RegionBank:
         self.flat = FlatParams(groups)
         self.spec = ops.RegionPhaseSpec(self.R, self.d, self.m_time, 0, sensor_idx, motor_idx)
         self.coord = coord or ops.GradCoordinator()
-        self.coord.register(self.flat.begin_pass, self._finish_pass)
+        self.coord.register_flagged(self.flat.begin_pass, self._launch_wgrad, self._publish)
         self.S = 1
         self.tape: ops.Tape = None  # type: ignore
         self._anchor: torch.Tensor = None  # type: ignore
@@ -137,9 +137,11 @@ class RegionBank:
             g[lo:lo + n].add_(rows.view(g[lo:lo + n].shape))
         return sink
 
-    def _finish_pass(self) -> None:
+    def _launch_wgrad(self):
+        """End of a backward pass, phase 1: the deferred dW launch; returns the device-side touched flags [R]
+        (read by the GradCoordinator together with every other participant's, one host sync)."""
         if self.tape.pos == 0:
-            return
+            return None
         dev = self.flat.flat.device
         if self._touched is None or self._touched.device != dev:
             self._touched = torch.zeros(self.R, dtype=torch.uint8, device=dev)
@@ -147,7 +149,10 @@ class RegionBank:
         gW = self.flat.stacked_grad("W")
         ops.region_wgrad(self.tape, self.S, self.R, self.d, gW, self._touched)
         self.tape.reset()
-        touched = self._touched.bool().tolist()  # one host sync per backward pass
+        return self._touched
+
+    def _publish(self, touched) -> None:
+        """Phase 2: .grad views for the regions that took part (on any rank, under data parallelism)."""
         self.flat.publish("W", [t for t in touched for _ in range(4)])
         self.flat.publish("norm_w", touched)
         self.flat.publish("raw_decay", touched)

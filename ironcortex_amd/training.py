@@ -136,6 +136,8 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
                 target, gains = dp.mean(target), dp.mean(gains)
             if cfg.tau_kappa != 0.0:
                 prec = (model.bank.var[0] + EPS_DIV).reciprocal().mean(-1)
+                if dp is not None:  # region state is rank-local; tau is replicated state: use the mean precision
+                    prec = dp.mean(prec)
                 target = target + cfg.tau_kappa * (prec - cfg.tau_target_prec)
             new_tau = (1 - 0.01) * tau + 0.01 * target
             for r, ff in enumerate(model.reg_ff):
@@ -192,7 +194,13 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         verifier_loss = torch.tensor(0.0, device=device)
 
     total = λ.ff * ff_loss + λ.rtd * rtd_loss + λ.denoise * denoise_loss + λ.critic * critic_loss + λ.verify * verifier_loss
-    total.backward()
+    if dp is not None:
+        dp.attach(model)  # None-ness of every gradient made rank-consistent inside the backward's one host read
+    try:
+        total.backward()
+    finally:
+        if dp is not None:
+            dp.detach(model)
     model.finalize_grads()
     if dp is not None:
         dp.sync_grads(model)

@@ -18,8 +18,26 @@ from ironcortex_amd.region import RegionBank, RWKVRegionCell  # noqa: E402
 from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors  # noqa: E402
 
 
-def sweep(Rs, ks, Ss, d=256, iters=20, backward=False):
-    """Yields one dict per (R, S, k) point."""
+def mask_sets(S, R, k, rotate):
+    """rotate mask sets [S,R]: stream s of set i takes entries i*k..(i+1)*k-1 (cyclically) of its own seeded
+    permutation of the regions, so a region's weights come back only after every other region's have
+    been streamed -- with R = 512 (regions 512 MiB + W_edge 728 MiB) nothing the next iteration needs
+    is left in the 256 MiB Infinity Cache.  rotate = 1: the same active set every iteration."""
+    g = torch.Generator().manual_seed(0)
+    perms = [torch.randperm(R, generator=g) for _ in range(S)]
+    sets = []
+    for i in range(max(1, rotate)):
+        m = torch.zeros(S, R, dtype=torch.uint8)
+        for s in range(S):
+            idx = [(i * k + j) % R for j in range(k)]
+            m[s, perms[s][idx]] = 1
+        sets.append(m)
+    return sets
+
+
+def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
+    """Yields one dict per (R, S, k) point.  events=False: no HIP-event bracketing (the run is being
+    traced by rocprofv3 instead); the row then only carries the algorithmic bytes."""
     dev = torch.device("cuda", torch.cuda.current_device())
     for R in Rs:
         torch.manual_seed(0)
@@ -33,12 +51,8 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False):
         nin = torch.ones(d, device=dev)
         for S in Ss:
             for k in ks:
-                g = torch.Generator().manual_seed(0)
-                mask = torch.zeros(S, R, dtype=torch.uint8)
-                for s in range(S):
-                    mask[s, torch.randperm(R, generator=g)[:k]] = 1
-                mask = mask.to(dev)
-                H = torch.randn(S, R, d, device=dev) * mask.unsqueeze(-1)
+                masks = [m.to(dev) for m in mask_sets(S, R, k, rotate)]
+                Hs = [torch.randn(S, R, d, device=dev) * m.unsqueeze(-1) for m in masks]
                 sensor = torch.randn(S, d, device=dev)
                 bank.reset_state(dev, S)
                 bank.num, bank.den = torch.rand(S, R, d, device=dev), torch.rand(S, R, d, device=dev) + 0.5
@@ -46,7 +60,8 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False):
                 bank.dt = torch.randint(0, 8, (S, R), dtype=torch.int32, device=dev)
                 state0 = (bank.num, bank.den, bank.pred, bank.dt)
 
-                def run(grad):
+                def run(grad, i=0):
+                    mask, H = masks[i % len(masks)], Hs[i % len(masks)]
                     bank.num, bank.den, bank.pred, bank.dt = state0
                     if grad:
                         Hg = H.clone().requires_grad_(True)
@@ -60,22 +75,28 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False):
                             M = router.route(H, mask, coords)
                             bank.phase(M, sensor, nin, mask, 0.5)
 
-                for _ in range(3):
-                    run(backward)
+                for i in range(3):
+                    run(backward, i)
                 torch.cuda.synchronize()
-                hip.prof_select("")
-                hip.prof_enable(True)
-                hip.prof_read()
-                for _ in range(iters):
-                    run(backward)
-                prof = hip.prof_read()
+                if events:
+                    hip.prof_select("")
+                    hip.prof_enable(True)
+                    hip.prof_read()
+                for i in range(iters):
+                    run(backward, 3 + i)
+                torch.cuda.synchronize()
+                prof = hip.prof_read() if events else {}
                 hip.prof_enable(False)
-                uniq = int(mask.any(0).sum())
-                src_act = mask.bool()[:, router.src_idx]
-                e_uniq = int(src_act.any(0).sum())
-                pairs = int(mask.sum())
-                st = dict(u_f=uniq, n_f=pairs, u_b=uniq, n_b=pairs, e=e_uniq, q=0, R=R, afd=False, prec=False)
-                row = {"R": R, "S": S, "k": k, "d": d, "unique_regions": uniq, "unique_edges": e_uniq,
+                n_sets = float(len(masks))  # per-launch averages over the rotation
+                uniq = sum(int(m.any(0).sum()) for m in masks) / n_sets
+                e_uniq = sum(int(m.bool()[:, router.src_idx].any(0).sum()) for m in masks) / n_sets
+                e_pairs = sum(int(m.bool()[:, router.src_idx].sum()) for m in masks) / n_sets
+                q_uniq = sum(int(torch.zeros(R, device=dev).index_add_(0, router.dst_idx, m.bool()[:, router.src_idx].any(0).float()).gt(0).sum())
+                             for m in masks) / n_sets
+                pairs = sum(int(m.sum()) for m in masks) / n_sets
+                st = dict(u_f=uniq, n_f=pairs, u_b=uniq, n_b=pairs, e=e_uniq, ep=e_pairs, q=q_uniq, R=R, S=S, afd=False, prec=False)
+                row = {"R": R, "S": S, "k": k, "d": d, "rotate": len(masks), "backward": backward,
+                       "unique_regions": uniq, "unique_edges": e_uniq, "pairs": pairs, "edge_pairs": e_pairs,
                        "weights_MiB": {"regions": R * 4 * d * d * 4 / 2**20, "W_edge": router.E * d * d * 4 / 2**20},
                        "kernels": {}}
                 for name, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
@@ -84,9 +105,15 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False):
                     row["kernels"][name] = {"avg_us": round(us, 2), "alg_MB": round(ab / 1e6, 3),
                                             "GBs": round(ab / (us * 1e-6) / 1e9, 1) if ab else None,
                                             "frac": round(ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if ab else None}
+                if not events:  # priced for the summariser that reads rocprofv3's tables (scripts/sweep_profile.py)
+                    row["alg_bytes"] = {name: algorithmic_bytes(name, d, st) for name in SWEEP_KERNELS}
                 yield row
         del bank, router, cells
         torch.cuda.empty_cache()
+
+
+SWEEP_KERNELS = ("region_pro", "region_rkv", "region_out", "region_fin", "router_fwd", "region_out_bwd", "region_rkv_bwd",
+                 "region_pro_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_region", "wgrad_edge")
 
 
 def main():
@@ -97,8 +124,10 @@ def main():
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--backward", action="store_true")
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many disjoint active sets")
+    ap.add_argument("--no-events", action="store_true", help="no HIP-event bracketing (run under rocprofv3)")
     args = ap.parse_args()
-    for row in sweep(args.R, args.k, args.S, args.d, args.iters, args.backward):
+    for row in sweep(args.R, args.k, args.S, args.d, args.iters, args.backward, args.rotate, not args.no_events):
         print(json.dumps(row), flush=True)
 
 

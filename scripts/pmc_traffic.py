@@ -10,10 +10,18 @@ import json
 import sys
 
 
+# kernel function -> the library's kernel id (ic_common.h IcKid; bench.py reports by id).  k_front is the
+# gate + router-edge launch: id router_edge_fwd with precision routing (the bench config), router_fwd without.
+ALIAS = {"region_rkv_routed": "region_rkv", "router_fwd_ms": "router_fwd", "region_fin_chain": "region_fin",
+         "router_comb_bwd_serial": "router_comb_bwd", "router_combine_serial": "router_combine",
+         "gemv_multi": "gemv", "gemv_reg": "gemv", "gemv_chain1": "gemv", "heads": "token_rows",
+         "combine_gemv": "logits_combine", "front": "router_edge_fwd", "gate_fused": "gate_select"}
+
+
 def short(name: str) -> str:
-    n = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].strip()
     n = n[2:] if n.startswith("k_") else n
-    return {"region_rkv_routed": "region_rkv"}.get(n, n)  # same kernel id in the library's timing table
+    return ALIAS.get(n, n)
 
 
 def avg(path: str, counter: str):

@@ -72,3 +72,75 @@ def test_dp_exchange_world2():
     # replicas end identical
     for k in ("w", "bias", "a", "b"):
         assert torch.equal(res[0][k], res[1][k])
+
+
+def _worker_arena(rank, world, port, q):
+    """The train_step path: touched flags OR-ed across ranks inside GradCoordinator._end (one host read),
+    gradient arenas all-reduced in place, the rest through one packed bucket."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ironcortex_amd.flat import ArenaParameter, FlatParams
+        from ironcortex_amd.hip.ops import GradCoordinator
+        from ironcortex_amd.parallel import DataParallel
+        dp = DataParallel()
+        torch.manual_seed(7)
+        lin = torch.nn.Linear(4, 3)
+        a, b, c = (ArenaParameter(torch.randn(2, 2)) for _ in range(3))
+        flat = FlatParams({"W": [a, b, c]})
+        touched = torch.tensor([1, 1 if rank == 1 else 0, 0], dtype=torch.uint8)  # b only on rank 1, c nowhere
+
+        def launch():  # stands for the deferred dW kernels: writes the arena, returns the device-side flags
+            flat.stacked_grad("W")[0].fill_(rank + 1.0)
+            if rank == 1:
+                flat.stacked_grad("W")[1].fill_(4.0)
+            return touched
+
+        class Model:  # the two things DataParallel needs from a CortexReasoner
+            _coord = GradCoordinator()
+
+            @staticmethod
+            def grad_layout():
+                return [flat], [lin.weight, lin.bias]
+
+        m = Model()
+        m._coord.register_flagged(flat.begin_pass, launch, lambda fl: flat.publish("W", fl))
+        lin.weight.grad = torch.full((3, 4), float(rank + 1))
+        lin.bias.grad = None if rank == 0 else torch.ones(3)
+        dp.attach(m)
+        for f in m._coord._begin:
+            f()
+        m._coord._pending = True
+        m._coord._end()  # what the autograd engine calls at the end of a backward pass
+        dp.detach(m)
+        none_before = (b.grad is None, c.grad is None, lin.bias.grad is None)
+        dp.sync_grads(m)
+        q.put((rank, {"w": lin.weight.grad.clone(), "bias": lin.bias.grad.clone(), "a": a.grad.clone(),
+                      "b": b.grad.clone(), "c_none": c.grad is None, "none_before": none_before,
+                      "a_is_view": a.grad.data_ptr() == flat.grad_arena().data_ptr()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_arena_exchange_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_arena, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        o = res[r]
+        assert o["none_before"] == (False, True, False)             # rank-consistent None-ness before the exchange
+        assert o["a_is_view"]                                       # reduced in place: .grad still views the arena
+        assert torch.allclose(o["w"], torch.full((3, 4), 1.5))
+        assert torch.allclose(o["bias"], torch.full((3,), 0.5))
+        assert torch.allclose(o["a"], torch.full((2, 2), 1.5))
+        assert torch.allclose(o["b"], torch.full((2, 2), 2.0))
+        assert o["c_none"]
+    for k in ("w", "bias", "a", "b"):
+        assert torch.equal(res[0][k], res[1][k])
