@@ -54,7 +54,11 @@ enum {
 
 /* router flags */
 enum {
-  IC_RF_PRECISION = 1 << 0 /* enable_precision_routed_messages (gate.py:292-318) */
+  IC_RF_PRECISION = 1 << 0, /* enable_precision_routed_messages (gate.py:292-318) */
+  IC_RF_SHARED = 1 << 1     /* widx selects one of nW <= 8 matrices SHARED by many edges (edge_transform_mode
+                               "by_direction", gate.py:142-149,274-277) and no destination has two incoming edges
+                               with the same widx: without IC_RF_PRECISION the forward then runs as ONE GEMM
+                               [d, nW*d] x [nW*d, S*R] on the matrix cores (fp32 MFMA) instead of per-edge GEMVs */
 };
 
 const char* ic_last_error(void);
@@ -202,6 +206,8 @@ typedef struct ic_router_args {
   float* wgt;  /* [S,E]  routing weights (0 for inactive edges) */
   int64_t H_sstride;    /* elements between consecutive streams' H blocks; 0 = contiguous (R*d) */
   int64_t mask_sstride; /* bytes between consecutive streams' mask_prev rows; 0 = contiguous (R) */
+  int32_t nW;           /* number of weight matrices (needed with IC_RF_SHARED; 0 = E) */
+  int32_t pad_;
 } ic_router_args;
 int ic_router_fwd(const ic_router_args* a, ic_stream_t stream);
 
@@ -246,6 +252,7 @@ typedef struct ic_wgrad_edge_args {
   float* gW;                /* [nW,d,d] (which==2: [R,d,d]) accumulated in place */
   uint8_t* touched;         /* [nW] or [R] */
 } ic_wgrad_edge_args;
+/* (nW != E, which < 2: shared matrices -- one deterministic MFMA GEMM per matrix, dW_k += G_k X_k^T, no float atomics) */
 int ic_router_wgrad(const ic_wgrad_edge_args* a, ic_stream_t stream);
 
 /* ------------------------------------------------------------------ gate

@@ -204,9 +204,11 @@ enum IcKid {
   IC_KID_logits_combine,
   IC_KID_branch_score,
   IC_KID_steer_select,
+  IC_KID_router_mfma,
+  IC_KID_wgrad_mfma,
   IC_KID_COUNT
 };
-#define IC_KID_NAMES {"region_pro", "region_rkv", "region_out", "region_fin", "kwta_rows", "region_fin_bwd", "region_out_bwd", "region_mid_bwd", "region_rkv_bwd", "region_pro_bwd", "wgrad_region", "router_edge_fwd", "router_combine", "router_fwd", "router_comb_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_edge", "hebbian", "gate_scores", "gate_select", "mul", "rmsnorm_fwd", "rmsnorm_bwd", "goodness_fwd", "goodness_bwd", "gemv", "ws_write", "token_rows", "logits_combine", "branch_score", "steer_select"}
+#define IC_KID_NAMES {"region_pro", "region_rkv", "region_out", "region_fin", "kwta_rows", "region_fin_bwd", "region_out_bwd", "region_mid_bwd", "region_rkv_bwd", "region_pro_bwd", "wgrad_region", "router_edge_fwd", "router_combine", "router_fwd", "router_comb_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_edge", "hebbian", "gate_scores", "gate_select", "mul", "rmsnorm_fwd", "rmsnorm_bwd", "goodness_fwd", "goodness_bwd", "gemv", "ws_write", "token_rows", "logits_combine", "branch_score", "steer_select", "router_mfma", "wgrad_mfma"}
 
 // Optional live kernel timing with HIP events on the launch stream (ic_prof_* in the header).
 extern bool g_ic_prof_on;
@@ -234,6 +236,10 @@ static inline int ic_ceil_div(int a, int b) { return (a + b - 1) / b; }
 // library-internal (heads.hip): looks up, once per device, the address of the static scratch array of
 // ic_heads_fwd_static on the current device
 __attribute__((visibility("hidden"))) int ic_heads_static_setup(float** out);
+
+// library-internal (router_mfma.hip): the shared-matrix (by_direction) forward / weight-gradient GEMMs on MFMA
+__attribute__((visibility("hidden"))) int ic_router_shared_fwd_launch(const ic_router_args* a, hipStream_t st);
+__attribute__((visibility("hidden"))) int ic_wgrad_shared_launch(const ic_wgrad_edge_args* a, hipStream_t st);
 
 // library-internal: gate + router edge launch of ic_front_fwd, with or without the combine launch
 __attribute__((visibility("hidden"))) int ic_front_launch(const ic_gate_args* g, const ic_router_args* a,

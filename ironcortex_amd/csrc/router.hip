@@ -654,19 +654,7 @@ __global__ __launch_bounds__(256) void k_wgrad_edge(ic_wgrad_edge_args a) {
   }
   if (!any) return;
   float* out = a.gW + ((size_t)m * d + row0) * d;
-  const bool shared = (a.which != 2) && (a.nW != a.E);
-  if (shared) {  // several edges feed one matrix (by_direction): float atomics
-#pragma unroll
-    for (int j = 0; j < DCH; ++j) {
-      const int c = 4 * lane + 256 * j;
-      if (c < d) {
-        atomicAdd(out + c, acc0.v[j].x); atomicAdd(out + c + 1, acc0.v[j].y);
-        atomicAdd(out + c + 2, acc0.v[j].z); atomicAdd(out + c + 3, acc0.v[j].w);
-        atomicAdd(out + d + c, acc1.v[j].x); atomicAdd(out + d + c + 1, acc1.v[j].y);
-        atomicAdd(out + d + c + 2, acc1.v[j].z); atomicAdd(out + d + c + 3, acc1.v[j].w);
-      }
-    }
-  } else {
+  {  // one workgroup per matrix slice (shared matrices go through k_wgrad_shared_mfma): plain read-modify-write
     RowFrag<DCH> cur;
     load_row(cur, out, d, lane);
 #pragma unroll
@@ -750,6 +738,10 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
     if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
     else if (a->d <= 512) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<2>, gcomb, dim3(256), 0, st, *a));
     else IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<4>, gcomb, dim3(256), 0, st, *a));
+  } else if ((a->flags & IC_RF_SHARED) && a->E > 0) {  // by_direction: one GEMM on the matrix cores
+    IC_REQUIRE(a->nW >= 1 && a->nW <= 8, "ic_router_fwd: IC_RF_SHARED needs 1 <= nW <= 8 (nW=%d)", a->nW);
+    int rc2 = ic_router_shared_fwd_launch(a, st);
+    if (rc2) return rc2;
   } else {
     IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL(k_router_fwd_ms<DCH>, dim3(nsl, a->R), dim3(256), 0, st, *a)); });
   }
@@ -761,8 +753,9 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
 // routed region kernel that follows on the same stream.
 int ic_front_launch(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream, bool combine) {
   IC_REQUIRE(g != nullptr && a != nullptr, "ic_front_fwd: NULL args");
-  if (g->R > 64 || a->E == 0) {
-    IC_REQUIRE(combine, "ic_front_fwd: no fused launch for R=%d, E=%d", g->R, a->E);  // big maps: the gate's scores want the whole chip (ic_gate_fwd)
+  if (g->R > 64 || a->E == 0 || ((a->flags & IC_RF_SHARED) && !(a->flags & IC_RF_PRECISION))) {
+    // big maps: the gate's scores want the whole chip (ic_gate_fwd); shared matrices: the router is an MFMA GEMM
+    IC_REQUIRE(combine, "ic_front_fwd: no fused launch for R=%d, E=%d", g->R, a->E);
     int rc = ic_gate_fwd(g, stream);
     return rc ? rc : ic_router_fwd(a, stream);
   }
@@ -843,6 +836,14 @@ extern "C" int ic_router_wgrad(const ic_wgrad_edge_args* a, ic_stream_t stream) 
   IC_REQUIRE(a->tape_g && a->tape_H && a->tape_eact && a->visited && a->gW && a->touched,
              "ic_router_wgrad: NULL pointer");
   IC_REQUIRE(a->which == 2 || (a->src && a->widx), "ic_router_wgrad: NULL edge table");
+  if (a->which != 2 && a->nW != a->E) {  // shared matrices (by_direction): one deterministic MFMA GEMM per matrix
+    IC_REQUIRE(a->nW >= 1 && a->nW <= 64 && a->E <= 4096, "ic_router_wgrad: shared matrices need nW in [1,64] and E <= 4096 (nW=%d, E=%d)",
+               a->nW, a->E);
+    int rc = ic_wgrad_shared_launch(a, (hipStream_t)stream);
+    if (rc) return rc;
+    IC_LAUNCH_CHECK("ic_router_wgrad");
+    return IC_OK;
+  }
   IC_DISPATCH_DCH(a->d, {
     IC_TIMED(IC_KID_wgrad_edge, (hipStream_t)stream, hipLaunchKernelGGL(k_wgrad_edge<DCH>, dim3(ic_ceil_div(a->d, 8), ny), dim3(256), 0,
                        (hipStream_t)stream, *a));

@@ -1,0 +1,204 @@
+// Shared-matrix edge transforms on the matrix cores (reference gate.py:142-159,274-281: the
+// by_direction mode keeps 6 d x d matrices, one per hex direction, shared by every edge of that
+// direction).  With a shared matrix the per-edge GEMVs of the per_edge mode become true GEMMs:
+//
+//   forward   M^T[d, N] = sum_k  W_k [d,d]  x  X_k [d,N]      N = S*R (stream, destination) columns,
+//             X_k[:, n] = ebias_e * H[s, src_e] for the in-edge e of n's destination with widx[e] == k
+//             whose sender was active (a zero column otherwise).  Output-stationary: one workgroup
+//             owns a 128 x 32 tile of M^T and walks K = nW*d; no per-edge message buffer, no atomics.
+//   wgrad     dW_k[d,d] += G_k [d,P] x X_k^T [P,d]            P = (tape slot, stream, edge of direction k)
+//             pairs; one workgroup owns a 128 x 32 tile of dW_k and walks all pairs in a fixed
+//             order: deterministic (replaces the float atomics of the GEMV kernel for shared matrices).
+//
+// fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 (64 MACs per lane and instruction).  A wave owns a
+// 32 x 32 accumulator tile; A (weights / gradient columns) and B (gathered sender rows) are staged through
+// LDS in 32-wide K chunks, rows padded to 33 floats so the MFMA operand reads are bank-conflict free.
+#include "ic_common.h"
+#include "ic_route.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr int kTM = 128, kTN = 32, kTK = 32, kMaxShared = 8;
+
+// MFMA operand layout (wave64, 32x32x2): lane l supplies A[l % 32][l / 32] and B[l / 32][l % 32];
+// accumulator register v of lane l is C[8 * (v / 4) + 4 * (l / 32) + v % 4][l % 32].
+__device__ __forceinline__ void mfma_chunk(const float (*As)[kTK + 1], const float (*Bs)[kTN + 1], int wave, int lane,
+                                           v16f& acc) {
+  const int ai = wave * 32 + (lane & 31), kh = lane >> 5, bj = lane & 31;
+#pragma unroll
+  for (int kk = 0; kk < kTK; kk += 2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[ai][kk + kh], Bs[kk + kh][bj], acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a) {
+  __shared__ float As[kTM][kTK + 1];
+  __shared__ float Bs[kTK][kTN + 1];
+  __shared__ int tsrc[kMaxShared][kTN];
+  __shared__ float tscale[kMaxShared][kTN];
+  __shared__ int any_k[kMaxShared];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = a.d, N = a.S * a.R;
+  const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * kTN;
+  if (tid < kMaxShared) any_k[tid] = 0;
+  __syncthreads();
+  {  // per column and shared matrix: the sender row and bias of the (unique) active in-edge, or -1
+    const int c = tid & 31, k = tid >> 5, n = col0 + c;
+    int srow = -1;
+    float sc = 0.f;
+    if (k < a.nW && n < N) {
+      const int s = n / a.R, r = n % a.R;
+      for (int e = a.dst_off[r]; e < a.dst_off[r + 1]; ++e) {
+        if (a.widx[e] == k && prev_on(a, s, a.src[e])) {
+          srow = a.src[e];
+          sc = a.ebias[e];
+          break;
+        }
+      }
+    }
+    tsrc[k][c] = srow;
+    tscale[k][c] = sc;
+    if (srow >= 0) any_k[k] = 1;  // (same value from every writer)
+  }
+  __syncthreads();
+  v16f acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  for (int k = 0; k < a.nW; ++k) {
+    if (!any_k[k]) continue;  // workgroup-uniform
+    const float* W = a.W + (size_t)k * d * d;
+    for (int kk0 = 0; kk0 < d; kk0 += kTK) {
+      {  // A: rows row0.. of W_k, columns kk0..kk0+31; thread -> (row tid / 2, 16 columns)
+        const int r = tid >> 1, h = (tid & 1) * 16, grow = row0 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kk = kk0 + h + 4 * q;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (grow < d && kk < d) v = *reinterpret_cast<const float4*>(W + (size_t)grow * d + kk);
+          As[r][h + 4 * q + 0] = v.x; As[r][h + 4 * q + 1] = v.y; As[r][h + 4 * q + 2] = v.z; As[r][h + 4 * q + 3] = v.w;
+        }
+      }
+      {  // B: the gathered, bias-scaled sender rows; thread -> (column tid / 8, 4 k's)
+        const int c = tid >> 3, ks = (tid & 7) * 4, srow = tsrc[k][c], n = col0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (srow >= 0 && kk0 + ks < d) {
+          v = *reinterpret_cast<const float4*>(h_row(a, n / a.R, srow) + kk0 + ks);
+          const float sc = tscale[k][c];
+          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        }
+        Bs[ks + 0][c] = v.x; Bs[ks + 1][c] = v.y; Bs[ks + 2][c] = v.z; Bs[ks + 3][c] = v.w;
+      }
+      __syncthreads();
+      mfma_chunk(As, Bs, wave, lane, acc);
+      __syncthreads();
+    }
+  }
+  const int j = lane & 31, n = col0 + j;
+  if (n < N) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int i = row0 + wave * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
+      if (i < d) a.M[(size_t)n * d + i] = acc[v];
+    }
+  }
+}
+
+// dW_k += sum over (slot t, stream s, edge e with widx[e] == k, active) g[t,s,e,:] (x) H[t,s,src_e,:]
+__global__ __launch_bounds__(256) void k_wgrad_shared_mfma(ic_wgrad_edge_args a) {
+  __shared__ float As[kTM][kTK + 1];
+  __shared__ float Bs[kTK][kTN + 1];
+  __shared__ uint16_t elist[4096];
+  __shared__ int ecnt;
+  __shared__ uint8_t pact[kTK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = a.d, k = blockIdx.z;
+  const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * kTN;
+  if (wave == 0) {  // the edges of this matrix, in edge order (a fixed order of additions)
+    int cnt = 0;
+    for (int base = 0; base < a.E; base += 64) {
+      const int e = base + lane;
+      const bool on = e < a.E && a.widx[e] == k;
+      const unsigned long long b = __ballot(on);
+      if (on) elist[cnt + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)e;
+      cnt += __popcll(b);
+    }
+    if (lane == 0) ecnt = cnt;
+  }
+  __syncthreads();
+  const int cnt = ecnt;
+  const long long P = (long long)a.T * a.S * cnt;
+  v16f acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  int seen = 0;
+  for (long long p0 = 0; p0 < P; p0 += kTK) {
+    if (tid < kTK) {
+      const long long p = p0 + tid;
+      uint8_t on = 0;
+      if (p < P) {
+        const int ts = (int)(p / cnt), e = elist[p % cnt];
+        on = a.visited[ts / a.S] != 0 && a.tape_eact[(size_t)ts * a.E + e] != 0;
+      }
+      pact[tid] = on;
+    }
+    const int any = __syncthreads_or(tid < kTK ? (int)pact[tid] : 0);  // (pact written before the barrier inside)
+    if (!any) continue;  // workgroup-uniform
+    seen = 1;
+    {  // A[i][p] = g[pair p][row0 + i]; thread -> (pair tid % 32, 16 rows)
+      const int pp = tid & 31, i0 = (tid >> 5) * 16;
+      const long long p = p0 + pp;
+      const float* g = nullptr;
+      if (pact[pp]) {
+        const int ts = (int)(p / cnt), e = elist[p % cnt];
+        g = a.tape_g + ((size_t)ts * a.E + e) * d;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = row0 + i0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g && i < d) v = *reinterpret_cast<const float4*>(g + i);
+        As[i0 + 4 * q + 0][pp] = v.x; As[i0 + 4 * q + 1][pp] = v.y; As[i0 + 4 * q + 2][pp] = v.z; As[i0 + 4 * q + 3][pp] = v.w;
+      }
+    }
+    {  // B[p][j] = H[pair p's sender][col0 + j]; thread -> (pair tid / 8, 4 columns)
+      const int pp = tid >> 3, js = (tid & 7) * 4;
+      const long long p = p0 + pp;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pact[pp] && col0 + js < d) {
+        const int ts = (int)(p / cnt), e = elist[p % cnt];
+        v = *reinterpret_cast<const float4*>(a.tape_H + ((size_t)ts * a.R + a.src[e]) * d + col0 + js);
+      }
+      Bs[pp][js + 0] = v.x; Bs[pp][js + 1] = v.y; Bs[pp][js + 2] = v.z; Bs[pp][js + 3] = v.w;
+    }
+    __syncthreads();
+    mfma_chunk(As, Bs, wave, lane, acc);
+    __syncthreads();
+  }
+  if (!seen) return;
+  const int j = col0 + (lane & 31);
+  if (j < d) {
+    float* out = a.gW + (size_t)k * d * d;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int i = row0 + wave * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
+      if (i < d) out[(size_t)i * d + j] += acc[v];
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.touched[k] = 1;
+}
+
+}  // namespace
+
+// library-internal launchers (router.hip: ic_router_fwd / ic_router_wgrad)
+int ic_router_shared_fwd_launch(const ic_router_args* a, hipStream_t st) {
+  const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->S * a->R, kTN));
+  IC_BYTES(IC_KID_router_mfma, 4.0 * ((double)a->nW * a->d * a->d + 2.0 * a->S * a->R * a->d));
+  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_fwd_mfma, grid, dim3(256), 0, st, *a));
+  return IC_OK;
+}
+
+int ic_wgrad_shared_launch(const ic_wgrad_edge_args* a, hipStream_t st) {
+  const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->d, kTN), a->nW);
+  IC_TIMED(IC_KID_wgrad_mfma, st, hipLaunchKernelGGL(k_wgrad_shared_mfma, grid, dim3(256), 0, st, *a));
+  return IC_OK;
+}

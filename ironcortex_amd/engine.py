@@ -339,7 +339,7 @@ class LoopEngine:
             ga = new("ic_gate_args", S=1, R=R, d=d, sensor_idx=m.io_idxs["sensor"], motor_idx=m.io_idxs["motor"],
                      force_io=1, w1=gate.w1, w2=gate.w2, w3=gate.w3, w4=gate.w4, gain_ema=gate.gain_ema,
                      homeo=gate.homeo, nbr_off=off, nbr=nbr)
-            rspec = ops.RouterSpec(R, d, E, router.nW, router.enable_precision_routed_messages)
+            rspec = router.spec()
             ra = ops._router_args(rspec, tables, rP, 1)
             P = dict(bP)
             P["norm_in_w"] = norm_in_w
@@ -987,7 +987,7 @@ class LoopEngine:
         b.f.sensor = s.sensor.data_ptr()
         b.gM, b.ghpre, b.slab2, b.slab, b.slab_rt = WP["gM"], WP["ghpre"], WP["slab2"], WP["slab"], WP["slab_rt"]
         rb = new("ic_router_bwd_args")
-        rspec = ops.RouterSpec(R, d, E, router.nW, prec)
+        rspec = router.spec()
         if E > 0:
             rb.f = ops._router_args(rspec, tables, rP, 1)
             rb.f.ebias = s.ebias.data_ptr()
@@ -1306,7 +1306,7 @@ class LoopEngine:
 
         if E > 0:
             rb = new("ic_router_bwd_args")
-            rspec = ops.RouterSpec(R, d, E, router.nW, prec)
+            rspec = router.spec()
             rb.f = ops._router_args(rspec, tables, rP, S)
             rb.f.ebias = s0.ebias.data_ptr()
             rb.f.M = WP["gM"]  # unused by the backward, must be non-NULL

@@ -201,11 +201,20 @@ class Router(FastAttrs, nn.Module):
         if deg > 8:
             raise ValueError("Router: at most 8 incoming edges per region are supported")
         i32 = lambda x: torch.tensor(x if len(x) else [0], dtype=torch.int32, device=dev)
+        # shared matrices as ONE GEMM (IC_RF_SHARED): needs every destination's incoming edges to use distinct
+        # matrices (true on a hex map: one neighbour per direction); otherwise the per-edge GEMV kernel
+        self._shared_gemm = (self.edge_transform_mode == "by_direction" and E > 0 and all(
+            len({widx[e] for e in range(dst_off[r], dst_off[r + 1])}) == dst_off[r + 1] - dst_off[r] for r in range(R)))
         self._tables = {"dst_off": i32(dst_off), "src": i32(src), "widx": i32(widx), "src_off": i32(src_off),
                         "src_edges": i32(src_edges), "dst_of_edge": i32(dst),
                         "widx_long": torch.tensor(widx if E else [0], dtype=torch.long, device=dev)}
         self._tables_key = key
         return self._tables
+
+    def spec(self) -> ops.RouterSpec:
+        """Static description for the C calls (the edge tables must have been built: _edge_tables)."""
+        return ops.RouterSpec(self.R, self.d, self.E, self.nW, self.enable_precision_routed_messages,
+                              shared_gemm=bool(getattr(self, "_shared_gemm", False)))
 
     def _edge_bias(self, reg_coords: torch.Tensor) -> torch.Tensor:
         """1 + fb_alpha * b(delta) per edge (gate.py:284-290); trig of the static geometry is cached."""
@@ -257,7 +266,7 @@ class Router(FastAttrs, nn.Module):
         if tape is None or tape.pos == 0:
             return None
         dev = self._flat.flat.device
-        spec = ops.RouterSpec(self.R, self.d, self.E, self.nW, self.enable_precision_routed_messages)
+        spec = self.spec()
         tables = self._tables
         tw = torch.zeros(self.nW, dtype=torch.uint8, device=dev)
         ops.router_wgrad(tape, spec, tables, self._tape_S, 0, self._flat.stacked_grad("W"), tw)
@@ -304,7 +313,7 @@ class Router(FastAttrs, nn.Module):
             return torch.stack([self._route_factorized(H[s], mask_prev[s].bool(), reg_coords) for s in range(S)])
         tables = self._edge_tables(reg_coords)
         ebias = self._cached_bias(reg_coords)
-        spec = ops.RouterSpec(self.R, self.d, self.E, self.nW, self.enable_precision_routed_messages)
+        spec = self.spec()
         box = dict(spec=spec, tables=tables, P=self._params(), mask_prev=mask_prev.contiguous(),
                    tape=self._get_tape(S, dev), coord=self._coord, grad_sink=self._grad_sink)
         if torch.is_grad_enabled():

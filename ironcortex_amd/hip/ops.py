@@ -12,7 +12,7 @@ from typing import Callable, Dict, List, Optional
 
 import torch
 
-from . import ENUMS, check, lib, new, stream_handle
+from . import ENUMS, check, lib, new, ptr, stream_handle
 
 IC_F_AFD = ENUMS["IC_F_AFD"]
 IC_F_RT = ENUMS["IC_F_RT"]
@@ -22,6 +22,12 @@ IC_F_KWTA_SOFT = ENUMS["IC_F_KWTA_SOFT"]
 IC_F_NOISE_VEC = ENUMS["IC_F_NOISE_VEC"]
 IC_F_NORM_IN = ENUMS["IC_F_NORM_IN"]
 IC_RF_PRECISION = ENUMS["IC_RF_PRECISION"]
+
+
+def _vp(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    """Device address of a tensor for a scalar-argument entry point.  Raises for a CPU tensor: a host address
+    handed to a kernel is a GPU memory fault, not an error code."""
+    return ctypes.c_void_p(ptr(t))
 
 
 def _call(name: str, args) -> None:
@@ -197,7 +203,7 @@ def _region_args(spec: RegionPhaseSpec, P: Dict[str, torch.Tensor], S: int, step
     for k in ("W", "norm_w", "raw_decay", "norm_in_w", "W_time", "pn_param", "on_param", "rpn_param", "ron_param"):
         t = P.get(k)
         if t is not None and t.numel() > 0:
-            setattr(a, k, t.data_ptr())
+            setattr(a, k, ptr(t))
     return a
 
 
@@ -246,7 +252,7 @@ class RegionPhaseFn(torch.autograd.Function):
                        surprise_o=surprise_o, last_dir=last_dir, last_norm=last_norm, dt_o=dt_o, **sv)
         for k, t in tensors.items():
             if t is not None:
-                setattr(a, k, t.data_ptr())
+                setattr(a, k, ptr(t))
         _call("ic_region_phase_fwd", a)
         box["dt_o"], box["surprise_o"] = dt_o, surprise_o
         box["last_dir"], box["last_norm"] = last_dir, last_norm
@@ -287,7 +293,7 @@ class RegionPhaseFn(torch.autograd.Function):
                    radius_var=radius_var, dt=box["dt"], radius_o=radius_o, **ctx.sv)
         for k, t in fin.items():
             if t is not None:
-                setattr(b.f, k, t.data_ptr())
+                setattr(b.f, k, ptr(t))
         cont = lambda t: None if t is None else t.contiguous()
         gin = dict(gH=cont(gH), gnum_o=cont(gnum_o), gden_o=cont(gden_o), gvar_o=cont(gvar_o),
                    gpred_o=cont(gpred_o), gradius_o=cont(gradius_o), gradius_var_o=cont(gradius_var_o))
@@ -310,7 +316,7 @@ class RegionPhaseFn(torch.autograd.Function):
         for k, t in {**gin, **out}.items():
             if t is not None:
                 keep.append(t)
-                setattr(b, k, t.data_ptr())
+                setattr(b, k, ptr(t))
         b.tape_g = tape.slot("g", slot).data_ptr()
         b.tape_x = tape.slot("x", slot).data_ptr()
         b.tape_o = tape.slot("o", slot).data_ptr()
@@ -346,12 +352,14 @@ def region_wgrad(tape: Tape, S: int, R: int, d: int, gW: torch.Tensor, touched: 
 
 # ============================================================================ router
 class RouterSpec:
-    def __init__(self, R: int, d: int, E: int, nW: int, precision: bool):
+    def __init__(self, R: int, d: int, E: int, nW: int, precision: bool, shared_gemm: bool = False):
         self.R, self.d, self.E, self.nW, self.precision = R, d, E, nW, precision
+        self.shared_gemm = shared_gemm  # by_direction on a map where the GEMM formulation applies (IC_RF_SHARED)
 
 
 def _router_args(spec: RouterSpec, T: Dict[str, torch.Tensor], P: Dict[str, torch.Tensor], S: int):
-    a = new("ic_router_args", S=S, R=spec.R, d=spec.d, E=spec.E, flags=IC_RF_PRECISION if spec.precision else 0)
+    flags = (IC_RF_PRECISION if spec.precision else 0) | (ENUMS["IC_RF_SHARED"] if spec.shared_gemm else 0)
+    a = new("ic_router_args", S=S, R=spec.R, d=spec.d, E=spec.E, flags=flags, nW=spec.nW)
     a.dst_off, a.src, a.widx = T["dst_off"].data_ptr(), T["src"].data_ptr(), T["widx"].data_ptr()
     a.W = P["W"].data_ptr()
     if spec.precision:
@@ -371,12 +379,12 @@ class RouterFn(torch.autograd.Function):
         ebias = ebias.contiguous()
         a = _router_args(spec, box["tables"], box["P"], S)
         M = _e(H, S, R, d)
-        a.H, a.mask_prev, a.M, a.ebias = H.data_ptr(), box["mask_prev"].data_ptr(), M.data_ptr(), ebias.data_ptr()
+        a.H, a.mask_prev, a.M, a.ebias = ptr(H), ptr(box["mask_prev"]), ptr(M), ptr(ebias)
         sv = {}
         if spec.precision:
             sv = dict(msg=_e(H, S, E, d), keyv=_e(H, S, E, d), q=_e(H, S, R, d), wgt=_z(H, S, E))
             for k, t in sv.items():
-                setattr(a, k, t.data_ptr())
+                setattr(a, k, ptr(t))
         if E > 0:
             _call("ic_router_fwd", a)
         else:
@@ -405,7 +413,7 @@ class RouterFn(torch.autograd.Function):
         b.f.H, b.f.mask_prev, b.f.ebias = H.data_ptr(), box["mask_prev"].data_ptr(), ebias.data_ptr()
         b.f.M = gM.data_ptr()  # unused by the backward, must be non-NULL
         for k, t in ctx.sv.items():
-            setattr(b.f, k, t.data_ptr())
+            setattr(b.f, k, ptr(t))
         nslab = bwd_nslab(d)
         gM = gM.contiguous()
         out = dict(gH=_e(H, S, R, d), g_ebias_part=_z(H, nslab, S, E), slab=_e(H, nslab, S, E, d))
@@ -413,7 +421,7 @@ class RouterFn(torch.autograd.Function):
             out.update(g_rawP_rows=_z(H, S, E, d), gHd=_e(H, S, R, d), slab_q=_e(H, nslab, S, R, d))
         b.gM = gM.data_ptr()
         for k, t in out.items():
-            setattr(b, k, t.data_ptr())
+            setattr(b, k, ptr(t))
         b.src_off, b.src_edges = box["tables"]["src_off"].data_ptr(), box["tables"]["src_edges"].data_ptr()
         b.tape_gmsg = tape.slot("gmsg", slot).data_ptr()
         b.tape_H = tape.slot("H", slot).data_ptr()
@@ -475,8 +483,8 @@ class KWTAFn(torch.autograd.Function):
         d = shape[-1]
         x2 = x.contiguous().view(-1, d)
         y, gate = torch.empty_like(x2), torch.empty_like(x2)
-        check(lib().ic_kwta_fwd(ctypes.c_void_p(x2.data_ptr()), ctypes.c_void_p(y.data_ptr()),
-                                ctypes.c_void_p(gate.data_ptr()), ctypes.c_int32(x2.shape[0]),
+        check(lib().ic_kwta_fwd(_vp(x2), _vp(y),
+                                _vp(gate), ctypes.c_int32(x2.shape[0]),
                                 ctypes.c_int32(d), ctypes.c_int32(int(k)), ctypes.c_int32(int(bool(soft))),
                                 ctypes.c_float(float(temp)), stream_handle()), "ic_kwta_fwd")
         ctx.save_for_backward(gate)
@@ -491,8 +499,8 @@ class KWTAFn(torch.autograd.Function):
         d = gate.shape[-1]
         g2 = gy.contiguous().view(-1, d)
         gx = torch.empty_like(g2)
-        check(lib().ic_kwta_bwd(None, ctypes.c_void_p(gate.data_ptr()), ctypes.c_void_p(g2.data_ptr()),
-                                ctypes.c_void_p(gx.data_ptr()), ctypes.c_int32(g2.shape[0]), ctypes.c_int32(d),
+        check(lib().ic_kwta_bwd(None, _vp(gate), _vp(g2),
+                                _vp(gx), ctypes.c_int32(g2.shape[0]), ctypes.c_int32(d),
                                 ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_float(1.0), stream_handle()),
               "ic_kwta_bwd")
         return gx.view(gy.shape), None, None, None
@@ -507,8 +515,8 @@ class RMSNormFn(torch.autograd.Function):
         w = w.contiguous()
         y = torch.empty_like(x2)
         inv = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
-        check(lib().ic_rmsnorm_fwd(ctypes.c_void_p(x2.data_ptr()), ctypes.c_void_p(w.data_ptr()),
-                                   ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(inv.data_ptr()),
+        check(lib().ic_rmsnorm_fwd(_vp(x2), _vp(w),
+                                   _vp(y), _vp(inv),
                                    ctypes.c_int32(x2.shape[0]), ctypes.c_int32(d), ctypes.c_float(float(eps)),
                                    stream_handle()), "ic_rmsnorm_fwd")
         ctx.save_for_backward(x2, w, inv)
@@ -520,9 +528,9 @@ class RMSNormFn(torch.autograd.Function):
         d = x2.shape[-1]
         g2 = gy.contiguous().view(-1, d)
         gx, gw_rows = torch.empty_like(x2), torch.empty_like(x2)
-        check(lib().ic_rmsnorm_bwd(ctypes.c_void_p(x2.data_ptr()), ctypes.c_void_p(w.data_ptr()),
-                                   ctypes.c_void_p(inv.data_ptr()), ctypes.c_void_p(g2.data_ptr()),
-                                   ctypes.c_void_p(gx.data_ptr()), ctypes.c_void_p(gw_rows.data_ptr()),
+        check(lib().ic_rmsnorm_bwd(_vp(x2), _vp(w),
+                                   _vp(inv), _vp(g2),
+                                   _vp(gx), _vp(gw_rows),
                                    ctypes.c_int32(x2.shape[0]), ctypes.c_int32(d), stream_handle()),
               "ic_rmsnorm_bwd")
         return gx.view(gy.shape), gw_rows.sum(0), None
@@ -536,7 +544,7 @@ class GoodnessFn(torch.autograd.Function):
         d = H.shape[-1]
         h2 = H.contiguous().view(-1, d)
         g = torch.empty(h2.shape[0], dtype=torch.float32, device=H.device)
-        check(lib().ic_goodness_fwd(ctypes.c_void_p(h2.data_ptr()), ctypes.c_void_p(g.data_ptr()),
+        check(lib().ic_goodness_fwd(_vp(h2), _vp(g),
                                     ctypes.c_int32(h2.shape[0]), ctypes.c_int32(d), stream_handle()),
               "ic_goodness_fwd")
         ctx.save_for_backward(h2)
@@ -549,8 +557,8 @@ class GoodnessFn(torch.autograd.Function):
         d = h2.shape[-1]
         gg = gg.contiguous().view(-1)
         gH = torch.empty_like(h2)
-        check(lib().ic_goodness_bwd(ctypes.c_void_p(h2.data_ptr()), ctypes.c_void_p(gg.data_ptr()),
-                                    ctypes.c_void_p(gH.data_ptr()), ctypes.c_int32(h2.shape[0]),
+        check(lib().ic_goodness_bwd(_vp(h2), _vp(gg),
+                                    _vp(gH), ctypes.c_int32(h2.shape[0]),
                                     ctypes.c_int32(d), stream_handle()), "ic_goodness_bwd")
         return gH.view(ctx.shape)
 
@@ -560,9 +568,9 @@ def hebbian_rank1(W: torch.Tensor, dst_of_edge: torch.Tensor, src: torch.Tensor,
     """In-place W[widx[e]] += sum_b coef[b,e] * outer(H[b,dst_e], H[b,src_e])."""
     B, R, d = H.shape
     E = src.shape[0]
-    check(lib().ic_hebbian_rank1(ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(dst_of_edge.data_ptr()),
-                                 ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(widx.data_ptr()),
-                                 ctypes.c_void_p(coef.contiguous().data_ptr()),
-                                 ctypes.c_void_p(H.contiguous().data_ptr()), ctypes.c_int32(B),
+    check(lib().ic_hebbian_rank1(_vp(W), _vp(dst_of_edge),
+                                 _vp(src), _vp(widx),
+                                 _vp(coef.contiguous()),
+                                 _vp(H.contiguous()), ctypes.c_int32(B),
                                  ctypes.c_int32(R), ctypes.c_int32(d), ctypes.c_int32(E), stream_handle()),
           "ic_hebbian_rank1")

@@ -212,3 +212,53 @@ def test_router_sweep_sizes_vs_oracle(R, S, k, prec):
               torch.stack([P["query_W"][r].grad if P["query_W"][r].grad is not None else zq for r in range(R)]).reshape(1, -1),
               what="g.query", tol=1e-4)
     PL.flush(tag)
+
+
+@pytest.mark.parametrize("R,S,d", [(36, 4, 256), (64, 8, 256), (10, 3, 48)])
+def test_router_by_direction_mfma_vs_oracle(R, S, d):
+    """edge_transform_mode="by_direction" (gate.py:142-149,274-277): the forward is ONE fp32-MFMA GEMM
+    [d, 6d] x [6d, S*R] (k_router_shared_fwd_mfma), the shared matrices' gradient one deterministic MFMA GEMM
+    per direction (k_wgrad_shared_mfma, no float atomics) -- against the per-stream oracle, and bit-identical
+    from run to run."""
+    from ironcortex_amd.gate import Router
+    from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
+    from oracle import hotpath as O
+    seed = 7900 + R + S
+    nb = hex_neighbors(R)
+    coords = hex_axial_coords(R)
+    router = Router(nb, d, R, edge_transform_mode="by_direction").to(DEV)
+    W_dir = gi.det(seed + 1, 6, d, d, kind="xavier")
+    t = dict(W_reg=gi.det(seed + 5, 8, 2), beta_cos=gi.det(seed + 6, 8, scale=0.3), beta_sin=gi.det(seed + 7, 8, scale=0.3))
+    with torch.no_grad():
+        router._flat.stacked("W").copy_(W_dir)
+        router.W_reg.copy_(t["W_reg"]); router.beta_cos.copy_(t["beta_cos"]); router.beta_sin.copy_(t["beta_sin"])
+    mask = gi.det(seed + 2, S, R, kind="rand") < 0.45
+    mask[S - 1] = False  # a stream with no active sender: zeros
+    H = gi.det(seed + 8, S, R, d) * mask.unsqueeze(-1)
+    gM = gi.det(seed + 9, S, R, d)
+    runs = []
+    for _ in range(2):
+        for p in router.parameters():
+            p.grad = None
+        Hg = H.to(DEV).requires_grad_(True)
+        M = router.route(Hg, mask.to(torch.uint8).to(DEV), coords.to(DEV))
+        assert router._shared_gemm  # the GEMM formulation is the path taken on a hex map
+        (M * gM.to(DEV)).sum().backward()
+        runs.append((M.detach().clone(), Hg.grad.clone(), torch.stack([l.weight.grad.clone() for l in router.W_dir])))
+    for a_, b_ in zip(runs[0], runs[1]):
+        assert torch.equal(a_, b_), "not reproducible from run to run"
+    M, gH, gW = runs[0]
+    assert torch.all(M[S - 1] == 0)
+    leaf = lambda x: x.clone().requires_grad_(True)
+    P = {"W_dir": [leaf(W_dir[k]) for k in range(6)], "W_reg": t["W_reg"], "beta_cos": leaf(t["beta_cos"]), "beta_sin": leaf(t["beta_sin"])}
+    Hc = H.clone().requires_grad_(True)
+    Mc = torch.stack([O.router_messages(P, Hc[s], mask[s], coords, nb, mode="by_direction")[0] for s in range(S)])
+    (Mc * gM).sum().backward()
+    _TAG[0] = f"by_direction-mfma/R{R}/S{S}/d{d}"
+    close(M, Mc, what="M")
+    gclose(gH, Hc.grad, what="g.H")
+    gclose(router.beta_cos.grad, P["beta_cos"].grad, what="g.beta_cos")
+    gclose(router.beta_sin.grad, P["beta_sin"].grad, what="g.beta_sin")
+    zeros = torch.zeros(d, d)
+    gclose(gW, torch.stack([P["W_dir"][k].grad if P["W_dir"][k].grad is not None else zeros for k in range(6)]), what="g.W_dir")
+    PL.flush(_TAG[0])
