@@ -136,3 +136,58 @@ def synth_tensor(idx: int, shape, mean: float, std: float) -> torch.Tensor:
     g = torch.Generator().manual_seed(77000 + int(idx))
     u = torch.rand(tuple(int(x) for x in shape), generator=g) * 2 - 1
     return u * float(std * math.sqrt(3.0)) + float(mean)
+
+
+class DeterministicDraws:
+    """Makes a sampling loop (generate / diffusion_generate) reproducible across devices: inside the
+    context torch.randn_like / rand / randint draw from ONE seeded CPU generator (results moved to
+    the requested device), and torch.multinomial records the distribution it is given and returns
+    either a CPU draw (fixture generation) or the recorded sample of the reference run (`replay`),
+    so that the run under test follows the reference's trajectory exactly and only the
+    distributions are compared."""
+
+    def __init__(self, seed: int, replay=None):
+        self.g = torch.Generator().manual_seed(int(seed))
+        # multinomial draws from a generator of its own: replaying recorded samples must not shift the other draws
+        self.g2 = torch.Generator().manual_seed(int(seed) + 1)
+        self.replay = None if replay is None else [torch.as_tensor(r) for r in replay]
+        self.probs, self.samples = [], []
+        self._saved = {}
+
+    def __enter__(self):
+        import torch as T
+        g = self.g
+        self._saved = {k: getattr(T, k) for k in ("randn_like", "rand", "randint", "multinomial")}
+        o = self._saved
+
+        def randn_like(x, **k):
+            return T.randn(tuple(x.shape), generator=g).to(device=x.device, dtype=x.dtype)
+
+        def rand(*a, device=None, **k):
+            return o["rand"](*a, generator=g, **k).to(device) if device is not None else o["rand"](*a, generator=g, **k)
+
+        def randint(*a, device=None, **k):
+            out = o["randint"](*a, generator=g, **k)
+            return out.to(device) if device is not None else out
+
+        def multinomial(probs, num_samples, replacement=False, **k):
+            self.probs.append(probs.detach().float().cpu().clone())
+            i = len(self.samples)
+            if self.replay is not None:
+                s = self.replay[i].to(torch.long)
+            else:
+                s = o["multinomial"](probs.detach().float().cpu(), num_samples, replacement, generator=self.g2)
+            self.samples.append(s.clone())
+            return s.to(probs.device)
+
+        T.randn_like, T.rand, T.randint, T.multinomial = randn_like, rand, randint, multinomial
+        return self
+
+    def __exit__(self, *exc):
+        import torch as T
+        for k, v in self._saved.items():
+            setattr(T, k, v)
+        return False
+
+
+GEN_PROMPT = [ord(c) for c in "ROMEO:"]  # train_tiny_shakespeare.py:36 gen_prompt

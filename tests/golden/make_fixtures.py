@@ -340,6 +340,43 @@ def eval_fixture():
     save("eval.npz", blob)
 
 
+# ------------------------------------------------------------------ generation (BASELINE configs[4])
+def gen_fixture():
+    """Reference generate / diffusion_generate (generation.py:11-88, diffusion.py:20-77) with
+    enable_afa_attention=True under tests/golden/inputs.py::DeterministicDraws: per sampling step the
+    distribution handed to torch.multinomial and the sample drawn, plus the returned tokens.  Cases: the small
+    all-flags model and the exact 10M bench model with the scripts' call (prompt "ROMEO:", 100 tokens, 4 diffusion
+    steps; train_tiny_shakespeare.py:36-37,184-202)."""
+    import random
+    from ironcortex import CortexConfig, CortexReasoner
+    from ironcortex.diffusion import DiffusionConfig, diffusion_generate
+    from ironcortex.generation import generate
+    from tests.model_cases import BIG_CASES, load_case
+    blob = {}
+    for name, T_total, iters in (("allflags", 16, 3), ("bench10m", 100, 8)):
+        gold, cfg_amd, sd, _tok, _foc = load_case(name)
+        kw = MODEL_CASES[name] if name in MODEL_CASES else BIG_CASES[name][0]
+        cfg = CortexConfig(**kw)
+        prompt = torch.tensor([t % (cfg.V - 2) + 1 for t in gi.GEN_PROMPT], dtype=torch.long)
+        for fn_name in ("generate", "diffusion"):
+            torch.manual_seed(5); random.seed(5)
+            model = CortexReasoner(hex_neighbors(cfg.R), hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
+            model.load_state_dict(sd)
+            model.eval()
+            torch.manual_seed(123)
+            with gi.DeterministicDraws(900) as dd:
+                if fn_name == "generate":
+                    out = generate(model, prompt, T_total=T_total, max_outer_iters=iters)
+                else:
+                    out = diffusion_generate(model, prompt, T_total=T_total, diff_cfg=DiffusionConfig(steps=4))
+            pre = f"{name}.{fn_name}."
+            blob[pre + "tokens"] = npy(out)
+            blob[pre + "probs"] = np.stack([p.numpy() for p in dd.probs])
+            blob[pre + "samples"] = np.stack([s_.numpy() for s_ in dd.samples])
+            blob[pre + "num"] = npy(torch.stack([r.state_num for r in model.regions]))
+    save("generation.npz", blob)
+
+
 # ------------------------------------------------------------------ F9/F10 at full size
 def bigmodel_fixture():
     """The exact bench model (10M script config, T=256) and the default script config (R=36, d=256,
@@ -410,6 +447,6 @@ def bigmodel_fixture():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["region", "chain", "kwta", "gate", "router", "wiring", "model", "bigmodel", "eval"]
+    which = sys.argv[1:] or ["region", "chain", "kwta", "gate", "router", "wiring", "model", "bigmodel", "eval", "gen"]
     for w in which:
         globals()[w + "_fixture"]()

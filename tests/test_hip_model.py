@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from tests import parity_log as PL
+from tests.golden import inputs as gi
 from tests.model_cases import BIG_CASES, MODEL_CASES, grad_probes, load_case, seed_train
 
 pytestmark = pytest.mark.gpu
@@ -146,6 +147,39 @@ def test_evaluate_perplexity_vs_reference(name):
     PL.flush(tag)
     with pytest.raises(ValueError):
         ic.evaluate_perplexity(model, tokens[:, :1], torch.device(DEV))
+
+
+@pytest.mark.parametrize("engine", [True, False], ids=["engine", "general"])
+@pytest.mark.parametrize("fn_name", ["generate", "diffusion"])
+@pytest.mark.parametrize("name,T_total,iters", [("allflags", 16, 3), ("bench10m", 100, 8)])
+def test_generation_vs_reference(name, T_total, iters, fn_name, engine):
+    """BASELINE configs[4]: generate / diffusion_generate with enable_afa_attention=True against the REAL
+    reference's run (tests/golden/make_fixtures.py::gen_fixture): at every sampling step the distribution
+    handed to torch.multinomial (the sample itself is replayed from the reference run, all other draws come
+    from the same seeded CPU generator: tests/golden/inputs.py::DeterministicDraws), the number of steps, the
+    returned tokens and the region state left behind.  reference generation.py:11-88, diffusion.py:20-77."""
+    import ironcortex_amd as ic
+    gold, cfg, sd, _tok, _foc = load_case(name)
+    gen = np.load(os.path.join(os.path.dirname(__file__), "golden", "generation.npz"))
+    pre = f"{name}.{fn_name}."
+    model = build(cfg, sd)
+    model.engine.enabled = engine
+    model.eval()
+    prompt = torch.tensor([t % (cfg.V - 2) + 1 for t in gi.GEN_PROMPT], dtype=torch.long, device=DEV)
+    torch.manual_seed(123)
+    with gi.DeterministicDraws(900, replay=gen[pre + "samples"]) as dd:
+        if fn_name == "generate":
+            out = ic.generate(model, prompt, T_total=T_total, max_outer_iters=iters)
+        else:
+            out = ic.diffusion_generate(model, prompt, T_total=T_total, diff_cfg=ic.DiffusionConfig(steps=4))
+    ref_probs = gen[pre + "probs"]
+    assert len(dd.probs) == ref_probs.shape[0], "number of sampling steps differs"
+    tag = f"generation/{name}/{fn_name}/{'engine' if engine else 'general'}"
+    for i, p in enumerate(dd.probs):
+        PL.check(tag, f"probs:step{i}", p, ref_probs[i], TOL_STATE)
+    assert np.array_equal(out.cpu().numpy(), gen[pre + "tokens"])
+    PL.check(tag, "num", model.bank.num[0], gen[pre + "num"], TOL_STATE)
+    PL.flush(tag)
 
 
 def test_generation_smoke():
