@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-kernel-sweep", action="store_true")
+    ap.add_argument("--no-multi-stream", action="store_true")
     args = ap.parse_args()
 
     if os.environ.get("IC_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
@@ -238,6 +239,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- second, named measurement: the same train_step in multi-stream mode: the 2B loops of a
+    # step as independent lockstep streams.  NOT the reference's schedule (no sample-to-sample state carry), so
+    # it never becomes `value`; each stream is parity-checked against a batch-1 oracle run (tests/test_hip_multistream.py)
+    multi = None
+    if not args.no_multi_stream:
+        model.count_units(False)
+        model.stream_mode = "multi"
+        for _ in range(max(2, min(args.warmup, 3))):
+            ic.train_step(model, opt, tokens, lw, dev, dp=dp)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            m2 = ic.train_step(model, opt, tokens, lw, dev, dp=dp)
+        sync_all()
+        el2 = time.perf_counter() - t0
+        model.stream_mode = "strict"
+        if dp is not None:
+            import torch.distributed as dist
+            t = torch.tensor([el2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        multi = {"value": world * B * T * args.steps / el2, "unit": "tokens/s", "ms_per_step": 1e3 * el2 / args.steps,
+                 "steps": args.steps, "loss_total": m2["total"],
+                 "mode": "multi-stream: the 2B reasoning loops of a train_step as independent streams in lockstep, every "
+                         "one from the region state the step starts with (strict mode carries it from sample to sample)"}
+
     if rank == 0:
         tok_s = world * B * T * args.steps / elapsed
         out = {
@@ -321,6 +348,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.config, B, T, 1234)
         out["cpu_baseline"] = cb
+        out["multi_stream"] = multi
         print(json.dumps(out))
     if dp is not None:
         import torch.distributed as dist

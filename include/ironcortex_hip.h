@@ -208,6 +208,10 @@ typedef struct ic_router_args {
   int64_t mask_sstride; /* bytes between consecutive streams' mask_prev rows; 0 = contiguous (R) */
   int32_t nW;           /* number of weight matrices (needed with IC_RF_SHARED; 0 = E) */
   int32_t pad_;
+  const int32_t* in_slot; /* [S] or NULL (forward).  When set, stream s reads its input states / previous mask from
+                           block in_slot[s] of H / mask_prev (R*d floats / R bytes per block; the strides above are
+                           ignored): the streams of a multi-stream launch (independent reasoning loops run in
+                           lockstep) each continue from their own winner of the previous outer iteration. */
 } ic_router_args;
 int ic_router_fwd(const ic_router_args* a, ic_stream_t stream);
 
@@ -276,6 +280,12 @@ typedef struct ic_gate_args {
   int64_t H_sstride;       /* elements between the H blocks of consecutive streams; 0 = contiguous (R*d).
                               Lets the branches of one outer iteration, whose input states sit in
                               arbitrary step slots, go through ONE launch. */
+  /* multi-stream launches (independent reasoning loops in lockstep): per-stream values instead of the scalars
+   * above; each may be NULL.  Device-readable memory (pinned host memory is fine: a few words per launch). */
+  const int32_t* in_slot;   /* [S] stream s reads H block in_slot[s] (R*d floats per block; H_sstride ignored) */
+  const float* t5_s;        /* [S] replaces t5 (each loop has its own critic value) */
+  const float* t6_s;        /* [S] replaces t6 (its own uncertainty) */
+  const int32_t* k_total_s; /* [S] replaces k_total (its own burst) */
 } ic_gate_args;
 int ic_gate_scores(const ic_gate_args* a, ic_stream_t stream);
 /* Gate.select_k + nms_topk (gate.py:70-87, utils.py:107-124).  Total order: score
@@ -391,6 +401,8 @@ typedef struct ic_heads_args {
   int64_t slots_in_sstride; /* elements between consecutive streams' slots_in blocks */
   float* ws_mean;           /* [S,d] or NULL: mean of the active rows of H (zeros when none) -- the planner's
                                input for the NEXT outer iteration should this step win (model.py:344-349) */
+  const int32_t* par_slot;   /* [S] or NULL: stream s's parent states are block par_slot[s] of H_par (R*d floats per block) */
+  const int32_t* slots_slot; /* [S] or NULL: its incoming workspace is block slots_slot[s] of slots_in (n_slots*d floats) */
 } ic_heads_args;
 int ic_heads_fwd(const ic_heads_args* a, ic_stream_t stream);
 /* ic_heads_fwd for callers that cannot allocate device memory (code under HIP graph capture, tight

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_gate_scores(ic_gate_args a) {
   if (row >= a.S * a.R) return;
   const int s = row / a.R, r = row % a.R;
   RowFrag<DCH> h;
-  load_row(h, a.H + (size_t)s * (a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d) + (size_t)r * a.d, a.d, lane);
+  load_row(h, gate_h_row(a, s, r), a.d, lane);
   float part = 0.f;
 #pragma unroll
   for (int j = 0; j < DCH; ++j)
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void k_gate_scores(ic_gate_args a) {
     sc = sc + a.w2 * a.gain_ema[r];
     sc = sc + a.w3 * focus;
     sc = sc - a.w4 * a.homeo[r];
-    sc = sc + a.t5;
-    sc = sc + a.t6;
+    sc = sc + gate_t5(a, s);
+    sc = sc + gate_t6(a, s);
     a.scores[row] = sc;
   }
 }

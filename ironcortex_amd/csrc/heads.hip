@@ -480,12 +480,16 @@ __device__ __forceinline__ void sq_rows(const ic_heads_args& a, int lane, int wa
 // Arguments of stream s of a batched call (ic_heads_args.S > 1): every pointer moved to that
 // stream's block.
 __device__ __forceinline__ ic_heads_args heads_stream(ic_heads_args a, int s) {
-  if (s == 0) return a;
   const size_t rd = (size_t)a.R * a.d, sd = (size_t)a.n_slots * a.d;
+  if (a.par_slot) a.H_par += (int64_t)a.par_slot[s] * (int64_t)rd;  // multi-stream: parents by block index
+  else a.H_par += (int64_t)s * (a.Hpar_sstride ? a.Hpar_sstride : (int64_t)rd);
+  if (a.slots_in) {
+    if (a.slots_slot) a.slots_in += (int64_t)a.slots_slot[s] * (int64_t)sd;
+    else a.slots_in += (int64_t)s * (a.slots_in_sstride ? a.slots_in_sstride : (int64_t)sd);
+  }
+  if (s == 0) return a;
   a.H += s * rd;
   a.mask += (size_t)s * a.R;
-  a.H_par += (int64_t)s * (a.Hpar_sstride ? a.Hpar_sstride : (int64_t)rd);
-  if (a.slots_in) a.slots_in += (int64_t)s * (a.slots_in_sstride ? a.slots_in_sstride : (int64_t)sd);
   if (a.slots_out) a.slots_out += s * sd;
   if (a.surprise) a.surprise += (size_t)s * a.R;
   a.z += (size_t)s * (a.Kf + a.Kf * a.V);

@@ -5,6 +5,14 @@
 
 namespace {
 
+// per-stream inputs of a multi-stream launch (ic_gate_args.in_slot / t5_s / t6_s / k_total_s), else the shared ones
+__device__ __forceinline__ const float* gate_h_row(const ic_gate_args& a, int s, int r) {
+  if (a.in_slot) return a.H + ((int64_t)a.in_slot[s] * a.R + r) * a.d;
+  return a.H + (size_t)s * (a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d) + (size_t)r * a.d;
+}
+__device__ __forceinline__ float gate_t5(const ic_gate_args& a, int s) { return a.t5_s ? a.t5_s[s] : a.t5; }
+__device__ __forceinline__ float gate_t6(const ic_gate_args& a, int s) { return a.t6_s ? a.t6_s[s] : a.t6; }
+
 // Stable descending rank by counting, then the greedy suppression walk on one lane (R <= 1024,
 // the walk stops after k selections).  sc[] holds the stream's scores; all threads call.
 __device__ __forceinline__ void gate_select_body(const ic_gate_args& a, int s, const float* sc, int* order,
@@ -27,7 +35,8 @@ __device__ __forceinline__ void gate_select_body(const ic_gate_args& a, int s, c
   __syncthreads();
   if (threadIdx.x == 0) {
     uint8_t* mask = a.mask + s * R;
-    int k = a.k_total > 0 ? a.k_total : 0;
+    const int kt = a.k_total_s ? a.k_total_s[s] : a.k_total;
+    int k = kt > 0 ? kt : 0;
     if (a.force_io) {  // gate.py:80-84
       mask[a.sensor_idx] = 1;
       mask[a.motor_idx] = 1;
@@ -56,7 +65,7 @@ __device__ __forceinline__ void gate_fused_body(const ic_gate_args& a, int s, fl
   for (int r = wave; r < a.R; r += 4) {
     const int row = s * a.R + r;
     RowFrag<DCH> h;
-    load_row(h, a.H + (size_t)s * (a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d) + (size_t)r * a.d, a.d, lane);
+    load_row(h, gate_h_row(a, s, r), a.d, lane);
     float part = 0.f;
 #pragma unroll
     for (int j = 0; j < DCH; ++j)
@@ -69,8 +78,8 @@ __device__ __forceinline__ void gate_fused_body(const ic_gate_args& a, int s, fl
       v = v + a.w2 * a.gain_ema[r];
       v = v + a.w3 * focus;
       v = v - a.w4 * a.homeo[r];
-      v = v + a.t5;
-      v = v + a.t6;
+      v = v + gate_t5(a, s);
+      v = v + gate_t6(a, s);
       a.scores[row] = v;
       sc[r] = v;
     }

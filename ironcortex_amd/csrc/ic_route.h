@@ -8,10 +8,12 @@ namespace {
 // Row r of stream s of the input states / previous mask; streams may be strided (the branches of
 // one outer iteration read their inputs from arbitrary step slots).
 __device__ __forceinline__ const float* h_row(const ic_router_args& a, int s, int r) {
+  if (a.in_slot) return a.H + ((int64_t)a.in_slot[s] * a.R + r) * a.d;
   const int64_t hs = a.H_sstride ? a.H_sstride : (int64_t)a.R * a.d;
   return a.H + (int64_t)s * hs + (size_t)r * a.d;
 }
 __device__ __forceinline__ bool prev_on(const ic_router_args& a, int s, int r) {
+  if (a.in_slot) return a.mask_prev[(int64_t)a.in_slot[s] * a.R + r] != 0;
   const int64_t ms = a.mask_sstride ? a.mask_sstride : (int64_t)a.R;
   return a.mask_prev[(int64_t)s * ms + r] != 0;
 }

@@ -134,7 +134,9 @@ class _Sample:
     """Record of one loop: what the backward needs to replay the steps in reverse."""
 
     __slots__ = ("chunk", "i0", "n", "parent", "best", "step_pos", "init", "H0", "mask0", "sensor", "ebias",
-                 "norm_in_w", "flags", "kwta_k", "kwta_temp", "keep", "ebias_grad", "zero_in")
+                 "norm_in_w", "flags", "kwta_k", "kwta_temp", "keep", "ebias_grad", "zero_in", "ts")
+    # step t of the loop sits in slot i0 + t * ts of its chunk (ts = 1: one loop after the other;
+    # ts = N: N loops in lockstep, run_lockstep)
 
 
 class LoopEngine:
@@ -150,7 +152,8 @@ class LoopEngine:
         self._pass = None  # accumulators of the backward pass in flight
         self._sess = None  # C structs shared by the loops between two reset()s
         self._vhat0 = None  # critic value of the all-zero input state (same for every loop of a session)
-        self._hs_ok = False
+        self._hs_all = {}   # heads set-ups by number of streams per launch
+        self._hs_ok = set()  # ... checked in full since the last reset()
         self._fa_buf = None
         self._batch = None  # loops of one reasoning_loop_batch call, differentiated as ONE node
         # A recorded loop of a batch does not wait for its last iteration's scores: the winner is
@@ -159,7 +162,7 @@ class LoopEngine:
         self._pending = None
         self._events = None
         self._wsb = None
-        self.counters = {"batch_bwd": 0, "loop_bwd": 0}  # backward passes taken all-loops-at-once / loop by loop
+        self.counters = {"batch_bwd": 0, "loop_bwd": 0, "lockstep": 0}  # backward passes taken all-loops-at-once / loop by loop
         model._coord.register(self._begin_pass, self._finish_pass)
 
     # ------------------------------------------------------------------ applicability
@@ -198,7 +201,7 @@ class LoopEngine:
         self.flush_units()
         self._sess = None
         self._vhat0 = None
-        self._hs_ok = False  # parameters may have moved since: _heads_setup checks every pointer again
+        self._hs_ok = set()  # parameters may have moved since: _heads_setup checks every pointer again
         if self._arena is not None:
             self._arena.reset()
 
@@ -555,6 +558,7 @@ class LoopEngine:
             s.keep = (focus_any, tables, rP, bP)
             s.ebias_grad = bool(ebias.requires_grad)
             s.zero_in = H_prev is getattr(m, "_zero_H", None)
+            s.ts = 1
             if deferred:
                 slots_f = chunk.fields["slots"]
 
@@ -606,14 +610,19 @@ class LoopEngine:
                                          torch.tensor(float(grp.shape[0]), device=dev), grp.amax(1).sum()])
 
     # ------------------------------------------------------------------ loop heads (HIP, no autograd)
-    def _heads_setup(self, dev):
-        """C structs + scratch for ic_heads_fwd / ic_gemv_chain / ic_steer_select, rebuilt when the
-        parameters move (device change, deepcopy, load into new storage)."""
+    def _heads_setup(self, dev, nb: Optional[int] = None, lock: bool = False):
+        """C structs + scratch for ic_heads_fwd / ic_gemv_chain / ic_steer_select for launches of nb
+        streams (default: the branches of one loop), rebuilt when the parameters move (device change,
+        deepcopy, load into new storage).  The pinned score block `ls` holds, per stream: the branch
+        score at [0, n8), four statistics at [off_stats, +4*n8), the critic value of the stream as a
+        candidate at [off_vhat, +n8), the verifier energy at [off_energy, +n8), n8 = max(8, nb)."""
         m = self.model
         hf = m._heads_flat
-        nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
-        hs = getattr(self, "_hs", None)
-        if hs is not None and self._hs_ok and hs["key"][:3] == (dev, nb, hf.flat.data_ptr()):
+        if nb is None:
+            nb = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
+        ck = (nb, lock)  # (run_lockstep keeps its own structs: it leaves per-stream index arrays in them)
+        hs = self._hs_all.get(ck)
+        if hs is not None and ck in self._hs_ok and hs["key"][:3] == (dev, nb, hf.flat.data_ptr()):
             return hs  # checked in full since the last reset()
         hf.reflat()  # no-op while every facet / region-head Parameter still views the arena
         mods = [m.lm_head.gate]
@@ -623,15 +632,17 @@ class LoopEngine:
         if m.verify is not None:
             mods += [m.verify.net[0], m.verify.net[1], m.verify.net[3], m.verify.net[5]]
         key = (dev, nb, hf.flat.data_ptr()) + tuple(p.data_ptr() for l in mods for p in (l.weight, l.bias))
-        self._hs_ok = True
+        self._hs_ok.add(ck)
         if hs is not None and hs["key"] == key:
             return hs
         R, d, V, Kf = m.R, m.d, m.V, m.lm_head.Kf
+        n8 = max(8, nb)
+        o_stats, o_vhat, o_energy = n8, 5 * n8, 6 * n8
         z = lambda *s: torch.zeros(*s, device=dev)
         # per-branch scratch blocks are contiguous: branch b of a batched call uses block b
         # planner / critic scratch: one block per candidate branch (the chain runs for both branches
         # of an outer iteration before their scores say which one steers the next iteration)
-        buf = dict(ls=torch.zeros(64).pin_memory(), ws_prev=z(nb, d), motor=z(d), p_h=z(nb, d), p=z(nb, d), g_h=z(nb, 2 * d), g=z(nb, d),
+        buf = dict(ls=torch.zeros(8 * n8).pin_memory(), ws_prev=z(nb, d), motor=z(d), p_h=z(nb, d), p=z(nb, d), g_h=z(nb, 2 * d), g=z(nb, d),
                    c_h=z(nb, 2 * d),
                    z=z(nb, Kf + Kf * V), per_region=z(nb, R, V), probs=z(nb, V), aux=z(nb, 4), gsq=z(nb, 2 * R))
         P = {k: t.data_ptr() for k, t in buf.items()}
@@ -675,7 +686,7 @@ class LoopEngine:
             desc(steer[2], mods[3], [(P["p"], d), (P["ws_prev"], d)], P["g_h"], gelu)
             desc(steer[3], mods[4], [(P["g_h"], 2 * d)], P["g"], none)
             desc(steer[4], mods[5], [(P["ws_prev"], d), (P["g"], d)], P["c_h"], gelu)  # heads.py:69-70
-            desc(steer[5], mods[6], [(P["c_h"], 2 * d)], P["ls"] + 40 * 4, none)  # v_hat of candidate b at ls[40 + b]
+            desc(steer[5], mods[6], [(P["c_h"], 2 * d)], P["ls"] + o_vhat * 4, none)  # v_hat of candidate b at ls[o_vhat + b]
             for g_, (xb, yb) in zip(steer, (((d,), d), ((d,), d), ((d, d), 2 * d), ((2 * d,), d), ((d, d), 2 * d),
                                              ((2 * d,), 1))):
                 g_.x0_bs, g_.y_bs = xb[0], yb
@@ -685,9 +696,9 @@ class LoopEngine:
         # layer i of the verifier next to layer i of the planner chain, for ic_gemv_multi (refreshed per call)
         pairs = [(G * 2)() for _ in range(3)] if (ver is not None and steer is not None) else None
         tail = (G * 3)() if steer is not None else None
-        self._hs = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods, nb=nb, pairs=pairs,
-                        tail=tail)
-        return self._hs
+        hs = self._hs_all[ck] = dict(key=key, buf=buf, P=P, ha=ha, steer=steer, ver=ver, sa=sa, keep=mods, nb=nb,
+                                     pairs=pairs, tail=tail, off=(o_stats, o_vhat, o_energy))
+        return hs
 
     def _drive(self, steps, in_ptrs, H_of, K_inner, dev, chunk, i0, trace_views=False, zero_in=False):
         """The control flow of reference model.py:329-460 over step ids, heads on the HIP library.
@@ -923,6 +934,363 @@ class LoopEngine:
         branches = [branches[i] for i in top]
         traces.append(keep(H_of(branches[0][1])))
         return branches[0][1], last, traces
+
+
+    # ------------------------------------------------------------------ multi-stream mode (lockstep loops)
+    MAX_LOCKSTEP_STREAMS = 64  # ic_heads_fwd takes at most 64 streams per launch
+
+    def lockstep_usable(self, dev, n_loops: int) -> bool:
+        m = self.model
+        C = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
+        if not self.enabled or dev.type != "cuda" or n_loops < 1 or C > 2:
+            return False
+        if m.cfg.profile or m.cfg.ff_dropout or m.router.edge_transform_mode == "factorized":
+            return False
+        if not m.cfg.train_deterministic_inner_loop and (m.plan is None or m.verify is None):
+            return False
+        if torch.is_grad_enabled() and not m._logits_detached:
+            return False
+        b = m.bank
+        if b.S == 1 and b.num.device == dev and any(
+                getattr(b, k).requires_grad for k in ("num", "den", "var", "pred", "radius", "radius_var")):
+            return False
+        return True
+
+    def _vhat_zero_state(self, dev, H_ptr: int, mask_ptr: int) -> float:
+        """Critic value of the all-zero input state (what every loop of a batch starts from)."""
+        if self._vhat0 is not None:
+            return self._vhat0
+        hs = self._heads_setup(dev)
+        sa, steer, ls = hs["sa"], hs["steer"], hs["buf"]["ls"]
+        L, st = lib(), stream_handle()
+        sa.n_cand = 1
+        sa.H_cand[0], sa.mask_cand[0] = H_ptr, mask_ptr
+        sa.scores = None
+        for g in steer:
+            g.nbatch = 1
+        rc = L.ic_steer_select(ctypes.byref(sa), st) or L.ic_gemv_chain(steer, 6, st)
+        if rc:
+            check(rc, "ic_steer_select/ic_gemv_chain")
+        torch.cuda.current_stream(dev).synchronize()
+        self._vhat0 = float(ls[hs["off"][1]])
+        return self._vhat0
+
+    def run_lockstep(self, K_inner: int, sensors: torch.Tensor, focus_any: torch.Tensor, aux_rows):
+        """Multi-stream mode: N INDEPENDENT reasoning loops advance in lockstep, each from
+        the region state / workspace the bank holds now and from all-zero H_prev.  Per outer iteration
+        the gate, router, heads, verifier and planner chain of all N * B_br (loop, branch) pairs are
+        one launch sequence; the region phase runs once per branch over the N loops (the branches of
+        one loop share its state chain, reference model.py:376-389, the loops do not).  The host reads
+        one pinned score block per iteration and steers every loop separately (winner, critic value,
+        uncertainty, burst, halting: model.py:371-392 per loop), handing the kernels per-stream parents
+        and gate scalars (ic_gate_args.in_slot / t5_s / t6_s / k_total_s).
+
+        Every loop computes what a batch-1 reasoning_loop from the same initial state computes; what
+        differs from reasoning_loop_batch's strict schedule is only that sample j does NOT start from
+        the state sample j-1 left behind.  Afterwards the bank holds the LAST loop's final state.
+
+        sensors [N,d]; focus_any [N] uint8; aux_rows [N,4] or None (verifier aux: mixer energy, -, attention
+        entropy, -).  Returns (H [N,R,d] -- one autograd node over `sensors` when grad is enabled --,
+        masks uint8 [N,R], last logits [N,V], traces: list of N lists)."""
+        m = self.model
+        cfg, bank, router, gate = m.cfg, m.bank, m.router, m.gate
+        dev = sensors.device
+        R, d, E = m.R, m.d, router.E
+        N = int(sensors.shape[0])
+        det = bool(cfg.train_deterministic_inner_loop)
+        C = 1 if det else max(1, cfg.B_br)
+        S, K = C * N, int(K_inner)
+        KC = K * C
+        if S > self.MAX_LOCKSTEP_STREAMS:
+            raise ValueError(f"run_lockstep: {N} loops x {C} branches > {self.MAX_LOCKSTEP_STREAMS} streams per launch")
+        grad = torch.is_grad_enabled()
+        L, st = lib(), stream_handle()
+        self.counters["lockstep"] += 1
+        self.resolve_pending()
+        if bank.S != 1 or bank.num.device != dev:
+            bank.flat.reflat()
+            bank.reset_state(dev, 1)
+        if not grad:
+            self.reset()
+        need = (KC + 1) * N
+        arena = self._get_arena(dev, KC)
+        if arena.chunk_steps < need:
+            self._rescue_state()
+            self._arena = arena = StepArena(self._shapes(), chunk_steps=need)
+        chunk, ib = arena.reserve(need, dev)
+        base = ib + N
+        f, CP, CS = chunk.fields, chunk.ptr, chunk.stride
+        assert CS["H"] == R * d * 4 and CS["mask"] == R
+        n_slots = m.work.slots.shape[0]
+
+        # ---- block of N copies of what every loop starts from (slots ib .. ib+N-1)
+        state_pairs = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o"), ("var", "var_o"), ("surprise", "surprise_o"),
+                       ("pred", "pred_o"), ("radius", "radius_o"), ("radius_var", "radius_var_o")]
+        with torch.no_grad():
+            for k_, ko in state_pairs:
+                if ko in f:
+                    f[ko][ib:ib + N] = getattr(bank, k_).detach().reshape((1,) + tuple(f[ko].shape[1:]))
+            f["H"][ib:ib + N].zero_()
+            f["mask"][ib:ib + N].zero_()
+            f["slots"][ib:ib + N] = m.work.slots.detach()
+
+        # ---- structs
+        tables = router._edge_tables(m.reg_coords)
+        ebias = router._cached_bias(m.reg_coords)
+        ebias_c = ebias.detach().contiguous()
+        norm_in_w = m.norm_in.weight
+        kw_k, kw_soft, kw_temp = bank.kwta_now()
+        flags = bank._flags(kw_soft, bank.cells[0].disable_kwta, True)
+        rP, bP = router._params(), bank.params()
+        off, nbr = gate._tables(dev)
+        afd, rt_, use_pred = bank.afd, bank.rt, bank.use_pred
+        rspec = router.spec()
+        prec = rspec.precision
+        fo = focus_any.to(_U8).reshape(1, N).expand(C, N).contiguous()  # stream s = b * N + j
+        Hb, Mb, Sb = CP["H"] + ib * CS["H"], CP["mask"] + ib * CS["mask"], CP["slots"] + ib * CS["slots"]
+        ga = new("ic_gate_args", S=S, R=R, d=d, sensor_idx=m.io_idxs["sensor"], motor_idx=m.io_idxs["motor"],
+                 force_io=1, w1=gate.w1, w2=gate.w2, w3=gate.w3, w4=gate.w4, gain_ema=gate.gain_ema,
+                 homeo=gate.homeo, nbr_off=off, nbr=nbr)
+        ga.focus_any, ga.H = fo.data_ptr(), Hb
+        ra = ops._router_args(rspec, tables, rP, S)
+        ra.ebias, ra.H, ra.mask_prev = ebias_c.data_ptr(), Hb, Mb
+        P = dict(bP)
+        P["norm_in_w"] = norm_in_w
+        fa = ops._region_args(bank.spec, P, N, 0.0, kw_k, flags, kw_temp)
+        sens_c = sensors.detach().float().contiguous()
+        fa.sensor = sens_c.data_ptr()
+        last_dir, last_norm = torch.zeros(N, R, d, device=dev), torch.zeros(N, R, device=dev)
+        fa.last_dir, fa.last_norm = last_dir.data_ptr(), last_norm.data_ptr()
+        ga_ref, ra_ref, fa_ref = ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(fa)
+
+        hs = self._heads_setup(dev, S, lock=True)
+        ha, ver, steer, HP, ls = hs["ha"], hs["ver"], hs["steer"], hs["P"], hs["buf"]["ls"]
+        if "ctl_host" not in hs["buf"]:  # [in_slot | k_total | t5 | t6] per stream; reused by every call (each ends in a sync)
+            hs["buf"]["ctl_host"] = torch.zeros(4 * S, dtype=_I32).pin_memory()
+            hs["buf"]["ctl_dev"] = torch.zeros(4 * S, dtype=_I32, device=dev)
+        ctl_host, ctl_dev = hs["buf"]["ctl_host"], hs["buf"]["ctl_dev"]
+        ci = ctl_host.numpy()
+        cf = ci.view(np.float32)
+        cp = ctl_dev.data_ptr()
+        ga.in_slot, ga.k_total_s, ga.t5_s, ga.t6_s = cp, cp + 4 * S, cp + 8 * S, cp + 12 * S
+        ra.in_slot = cp
+        pairs_, tail_ = hs["pairs"], hs["tail"]
+        o_stats, o_vhat, o_energy = hs["off"]
+        lsp = HP["ls"]
+        lsn = hs["buf"].get("ls_np")
+        if lsn is None:
+            lsn = hs["buf"]["ls_np"] = ls.numpy()
+        ha_ref = ctypes.byref(ha)
+        ha.S, ha.Hpar_sstride, ha.slots_in_sstride = S, 0, 0
+        ha.H_par, ha.par_slot = Hb, cp
+        ha.slots_in, ha.slots_slot = Sb, cp
+        ha.stats = lsp + o_stats * 4
+        aux_on = ver is not None and m.verify.aux_dim > 0
+        if aux_on:
+            ab = hs["buf"]["aux"]
+            ab.zero_()
+            if aux_rows is not None:
+                ab.view(C, N, 4).copy_(aux_rows.reshape(1, N, 4).to(dev))
+        ha.aux_surprise = HP["aux"] + 4 if aux_on else None
+        motor = m.io_idxs["motor"]
+
+        out_names = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o")]
+        if afd:
+            out_names += [("var", "var_o"), ("surprise", "surprise_o")]
+        if use_pred:
+            out_names += [("pred", "pred_o")]
+        if rt_:
+            out_names += [("radius", "radius_o"), ("radius_var", "radius_var_o")]
+        saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
+            + (["sterm"] if afd else [])
+        rsaved = ["msg", "keyv", "q", "wgt"] if prec else []
+        denom = float(max(1, cfg.K_inner - 1))
+        w5, w6 = gate.w5, gate.w6
+        sync = torch.cuda.current_stream(dev).synchronize
+        NAN = float("nan")
+
+        # ---- host-side record of every loop
+        pars = [[-1] * C for _ in range(N)]       # steps whose output feeds branch b of the coming iteration
+        parent = [[] for _ in range(N)]           # parent step of every executed step (the backward's chain)
+        u_mean, v_hat = [0.0] * N, [0.0] * N
+        done = [False] * N                        # the loop has halted (reference should_halt) or finished
+        halt_now = [False] * N
+        best, n_steps = [-1] * N, [0] * N
+        traces: List[List[torch.Tensor]] = [[] for _ in range(N)]
+        keep_tr = (lambda t: t) if (grad and m._logits_detached) else (lambda t: t.clone())
+        Hf = f["H"]
+
+        def settle(k_prev: int) -> None:
+            """Scores of iteration k_prev are in the pinned block: winner, next parents, u_mean, v_hat per loop."""
+            vals = lsn.tolist()
+            t0_ = k_prev * C
+            for j in range(N):
+                if done[j]:
+                    continue
+                if C == 2:
+                    top = [1, 0] if vals[N + j] > vals[j] else [0, 1]
+                else:
+                    top = [0]
+                w = t0_ + top[0]
+                best[j] = w
+                traces[j].append(keep_tr(Hf[base + w * N + j]))
+                if halt_now[j] or k_prev + 1 >= K:
+                    done[j] = True
+                    continue
+                pars[j] = [t0_ + i for i in top]
+                u_mean[j] = vals[o_stats + 4 * ((C - 1) * N + j)]
+                v_hat[j] = 0.0 if det else vals[o_vhat + top[0] * N + j]
+
+        if not det:
+            v0 = self._vhat_zero_state(dev, Hb, Mb)
+            v_hat = [v0] * N
+        k_last, was_planned = -1, False
+        with torch.no_grad():
+            for k in range(K):
+                if k > 0:
+                    polled = False
+                    if POLL_SYNC and was_planned:
+                        for _ in range(40000):
+                            w_ = lsn[o_vhat:o_vhat + S]
+                            if not (w_ != w_).any():
+                                polled = True
+                                break
+                    if not polled:
+                        sync()
+                    settle(k - 1)
+                    if all(done):
+                        break
+                # per-stream inputs of this iteration's launches
+                for j in range(N):
+                    if det:
+                        bias, burst = 0.0, 0
+                    else:
+                        bias, burst = v_hat[j], schedule_burst(u_mean[j], v_hat[j], R)
+                    for b in range(C):
+                        s_ = b * N + j
+                        p_ = pars[j][b]
+                        ci[s_] = j if p_ < 0 else N + p_ * N + j
+                        ci[S + s_] = max(0, cfg.k_active + burst)
+                        cf[2 * S + s_] = w5 * bias
+                        cf[3 * S + s_] = w6 * u_mean[j]
+                        if not done[j]:
+                            parent[j].append(p_)
+                gate.value_bias = 0.0 if det else v_hat[N - 1]
+                ctl_dev.copy_(ctl_host, non_blocking=True)
+                a0 = base + k * C * N
+                ga.scores, ga.mask = CP["scores"] + a0 * CS["scores"], CP["mask"] + a0 * CS["mask"]
+                if E > 0:
+                    ra.M = CP["M"] + a0 * CS["M"]
+                    for k_ in rsaved:
+                        setattr(ra, k_, CP[k_] + a0 * CS[k_])
+                    rc = L.ic_front_fwd(ga_ref, ra_ref, st)
+                else:
+                    rc = L.ic_gate_fwd(ga_ref, st)
+                if rc:
+                    check(rc, "ic_front_fwd")
+                fa.step_pos = float(k) / denom
+                for b in range(C):  # branch b of every loop: state from the block before (branch b-1 / last iteration)
+                    a = a0 + b * N
+                    fa.M, fa.mask, fa.H = CP["M"] + a * CS["M"], CP["mask"] + a * CS["mask"], CP["H"] + a * CS["H"]
+                    for k_, ko in state_pairs:
+                        if ko in CP:
+                            setattr(fa, k_, CP[ko] + (a - N) * CS[ko])
+                    for k_, ko in out_names:
+                        setattr(fa, ko, CP[ko] + a * CS[ko])
+                    for k_ in saved:
+                        setattr(fa, k_, CP[k_] + a * CS[k_])
+                    rc = L.ic_region_phase_fwd(fa_ref, st)
+                    if rc:
+                        check(rc, "ic_region_phase_fwd")
+                m.counters["inner_steps"] += sum(C for j in range(N) if not done[j])
+                for j in range(N):
+                    if not done[j]:
+                        n_steps[j] = (k + 1) * C
+                        halt_now[j] = (not det) and should_halt(None, u_mean[j], k, K)
+                planned = (not det) and k + 1 < K and not all(done[j] or halt_now[j] for j in range(N))
+                # heads of all S streams, the verifier and (planned) the planner chain of every candidate
+                ha.H, ha.mask = CP["H"] + a0 * CS["H"], CP["mask"] + a0 * CS["mask"]
+                ha.slots_out = CP["slots"] + a0 * CS["slots"]
+                ha.surprise = CP["surprise_o"] + a0 * CS["surprise_o"] if afd else None
+                ha.logits = CP["logits"] + a0 * CS["logits"]
+                ha.ws_mean = HP["ws_prev"] if planned else None
+                if planned:
+                    if POLL_SYNC:
+                        lsn[o_vhat:o_vhat + S] = NAN
+                    steer[0].nbatch = steer[1].nbatch = S
+                    rc = L.ic_heads_gemv_fwd(ha_ref, ctypes.byref(steer[0]), ctypes.byref(steer[1]), st)
+                else:
+                    rc = L.ic_heads_fwd(ha_ref, st)
+                if rc:
+                    check(rc, "ic_heads_fwd")
+                if ver is not None and not det:
+                    ver[0].x0 = CP["H"] + a0 * CS["H"] + motor * d * 4
+                    ver[2].y = lsp + o_energy * 4
+                    for g in ver:
+                        g.nbatch = S
+                    if not planned:
+                        rc = L.ic_verify_score(ver, 3, lsp + o_stats * 4, lsp, st)
+                        if rc:
+                            check(rc, "ic_verify_score")
+                    else:
+                        for g in steer:
+                            g.nbatch = S
+                        for i_ in range(3):
+                            pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_ + 2]
+                            rc = L.ic_gemv_multi(pairs_[i_], 2, lsp + o_stats * 4, lsp if i_ == 2 else None, st)
+                            if rc:
+                                check(rc, "ic_gemv_multi")
+                        tail_[0] = steer[5]
+                        rc = L.ic_gemv_chain(tail_, 1, st)
+                        if rc:
+                            check(rc, "ic_gemv_chain")
+                k_last, was_planned = k, planned
+            if not all(done):
+                sync()
+                for j in range(N):
+                    halt_now[j] = True
+                settle(k_last)
+
+        # ---- results; the bank continues from the last loop's final state (views of its last slot)
+        bslot = torch.tensor([base + best[j] * N + j for j in range(N)], device=dev)
+        lslot = torch.tensor([base + (n_steps[j] - 1) * N + j for j in range(N)], device=dev)
+        masks = f["mask"][bslot]
+        logits = f["logits"][lslot]
+        jl = N - 1
+        li = base + (n_steps[jl] - 1) * N + jl
+        nar = torch.narrow
+        bank.num, bank.den, bank.dt = nar(f["num_o"], 0, li, 1), nar(f["den_o"], 0, li, 1), nar(f["dt_o"], 0, li, 1)
+        if afd:
+            bank.var, bank.surprise = nar(f["var_o"], 0, li, 1), nar(f["surprise_o"], 0, li, 1)
+        if use_pred:
+            bank.pred = nar(f["pred_o"], 0, li, 1)
+        if rt_:
+            bank.radius, bank.radius_var = nar(f["radius_o"], 0, li, 1), nar(f["radius_var_o"], 0, li, 1)
+        if prec:
+            router._last_wgt = nar(nar(f["wgt"], 0, li, 1), 1, 0, E)
+        m.work.slots = f["slots"][base + best[jl] * N + jl]
+        self._state_in_arena = True
+        if not grad:
+            H_out = f["H"][bslot]  # (index copy: nothing below refers to the arena)
+            self._rescue_state()
+            return H_out, masks, logits, traces
+        samples = []
+        step_pos = [float(t // C) / denom for t in range(KC)]
+        zero_H = getattr(m, "_zero_H", None)
+        for j in range(N):
+            s = _Sample()
+            s.chunk, s.i0, s.ts, s.n, s.parent, s.best = chunk, base + j, N, n_steps[j], parent[j][:n_steps[j]], best[j]
+            s.step_pos = step_pos[:n_steps[j]]
+            s.init, s.H0, s.mask0, s.sensor = None, None, None, sens_c[j]
+            s.ebias, s.norm_in_w = ebias_c, norm_in_w
+            s.flags, s.kwta_k, s.kwta_temp = flags, kw_k, kw_temp
+            s.keep = (fo, tables, rP, bP, ctl_host, ctl_dev, last_dir, last_norm)
+            s.ebias_grad = bool(ebias.requires_grad)
+            s.zero_in = True
+            samples.append(s)
+        bt = {"samples": samples, "chunk": chunk, "base": base, "n_max": KC, "n_loops": N, "lockstep": True}
+        H_out = LoopBatchFn.apply(sensors, bank.anchor(dev), self, bt)
+        return H_out, masks, logits, traces
 
     # ------------------------------------------------------------------ backward
     def backward(self, s: _Sample, gH_final: torch.Tensor):
@@ -1200,9 +1568,11 @@ class LoopEngine:
 
     def backward_batch(self, bt, gH_all: torch.Tensor) -> torch.Tensor:
         """Backward of every recorded loop at once: step t of all S loops is one launch sequence
-        with S streams (spread sk = n_max slots apart in the arena, the tapes and the gradient
-        buffers), so a pass costs n_max launch sequences instead of S * n_max and every weight row
-        is read once per step for all loops.  Returns d/d sensors [S, d]."""
+        with S streams, so a pass costs n_max launch sequences instead of S * n_max and every weight
+        row is read once per step for all loops.  Two slot layouts (arena, tapes, gradient buffers):
+        loops recorded one after the other sit ss = n_max slots apart with consecutive steps in
+        consecutive slots (ts = 1); loops run in lockstep (run_lockstep) sit in consecutive slots
+        (ss = 1) with consecutive steps S slots apart (ts = S).  Returns d/d sensors [S, d]."""
         m = self.model
         bank, router = m.bank, m.router
         dev = gH_all.device
@@ -1212,6 +1582,13 @@ class LoopEngine:
         S, K = len(ss), bt["n_max"]
         V = S * K
         s0 = ss[0]
+        lock = bool(bt.get("lockstep"))
+        sS, tS = (1, S) if lock else (K, 1)  # slot of (loop s, step t) = base + s * sS + t * tS
+        # [S,K,...] <-> rows in slot order
+        to_v = (lambda x: x.transpose(0, 1).reshape((V,) + tuple(x.shape[2:]))) if lock else \
+            (lambda x: x.reshape((V,) + tuple(x.shape[2:])))
+        from_v = (lambda y: y.view((K, S) + tuple(y.shape[1:])).transpose(0, 1)) if lock else \
+            (lambda y: y.view((S, K) + tuple(y.shape[1:])))
         L, st = lib(), stream_handle()
         bank.coord.begin()
         ws = self._workspace_batch(dev, V)
@@ -1241,15 +1618,15 @@ class LoopEngine:
             zoff += pad(V * sz)
         best = torch.tensor([s.best for s in ss], device=dev)
         lanes = torch.arange(S, device=dev)
-        Z["gH"].view(S, K, R * d)[lanes, best] = gH_all.reshape(S, R * d)
+        from_v(Z["gH"])[lanes, best] = gH_all.reshape(S, R * d)
 
         # ---- tapes: one slot per (loop, step), laid out like the arena block
         tape = bank.tape
         t0 = tape.alloc_n(V, dev)
         steps = torch.arange(K, device=dev)
         live = steps[None, :] <= best[:, None]                      # [S,K]: steps that reach the loss
-        mk = chunk.fields["mask"][base:base + V].view(S, K, R) * live[:, :, None].to(_U8)
-        tape.buf["mask"][t0:t0 + V, 0].copy_(mk.view(V, R))          # the backward's own (masked) copy
+        mk = from_v(chunk.fields["mask"][base:base + V]) * live[:, :, None].to(_U8)           # [S,K,R]
+        tape.buf["mask"][t0:t0 + V, 0].copy_(to_v(mk))               # the backward's own (masked) copy
         tape.visited[t0:t0 + V].fill_(1)
         mask_ptr, mask_stride = tape.buf["mask"].data_ptr() + t0 * tape.buf["mask"].stride(0), tape.buf["mask"].stride(0)
         TB = {k: (tape.buf[k].data_ptr(), tape.buf[k].stride(0) * 4) for k in ("g", "x", "o")}
@@ -1261,9 +1638,9 @@ class LoopEngine:
             # where each stream's step reads its input states: the parent's slot (relative to base)
             pars = [list(s.parent) + [-1] * (K - s.n) for s in ss]                           # halted loops: padded
             par = torch.tensor(pars, dtype=torch.int64, device=dev)                           # [S,K]
-            slot = torch.where((par >= 0) & live, lanes[:, None] * K + par, torch.full_like(par, -1))
+            slot = torch.where((par >= 0) & live, lanes[:, None] * sS + par * tS, torch.full_like(par, -1))
             in_slot = slot.t().contiguous().to(torch.int32)                                   # [K,S]
-            rtape.visited[rt0:rt0 + V].copy_((slot >= 0).reshape(V).to(_U8))
+            rtape.visited[rt0:rt0 + V].copy_(to_v((slot >= 0).to(_U8)))
             r_live = [any(p >= 0 for p in col) for col in zip(*pars)]                         # host: per step
 
         # ---- structs
@@ -1274,7 +1651,7 @@ class LoopEngine:
         b = new("ic_region_bwd_args")
         b.f = ops._region_args(bank.spec, P, S, 0.0, s0.kwta_k, flags, s0.kwta_temp)
         b.f.sensor = sens.data_ptr()
-        b.sk = K
+        b.sk = sS
         b.gM, b.ghpre, b.slab2, b.slab, b.slab_rt = WP["gM"], WP["ghpre"], WP["slab2"], WP["slab"], WP["slab_rt"]
         saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
             + (["sterm"] if afd else [])
@@ -1286,20 +1663,20 @@ class LoopEngine:
         rows = ["g_norm_w_rows", "g_raw_decay_rows", "g_norm_in_rows"] + (["g_pn_rows", "g_on_rows"] if afd else []) \
             + (["g_rnoise_rows"] if rt_ else [])
         bimg = StructImage(b)
-        bimg.linear(("f", "M"), CP["M"] + base * CS["M"], CS["M"])
-        bimg.linear(("f", "mask"), mask_ptr, mask_stride)
-        for k, ko in state_in:  # input state of step t = output of slot t - 1 (t == 0: the slot before the block)
-            bimg.linear(("f", k), CP[ko] + (base - 1) * CS[ko], CS[ko])
+        bimg.linear(("f", "M"), CP["M"] + base * CS["M"], tS * CS["M"])
+        bimg.linear(("f", "mask"), mask_ptr, tS * mask_stride)
+        for k, ko in state_in:  # input state of step t = output of step t - 1 (t == 0: the slot(s) before the block)
+            bimg.linear(("f", k), CP[ko] + (base - tS) * CS[ko], tS * CS[ko])
         if rt_:
-            bimg.linear(("f", "radius_o"), CP["radius_o"] + base * CS["radius_o"], CS["radius_o"])
+            bimg.linear(("f", "radius_o"), CP["radius_o"] + base * CS["radius_o"], tS * CS["radius_o"])
         for k in saved:
-            bimg.linear(("f", k), CP[k] + base * CS[k], CS[k])
-        bimg.linear(("gH",), zp["gH"], R * d * 4)
-        bimg.linear(("gsens",), zp["gsens"], 2 * d * 4)
+            bimg.linear(("f", k), CP[k] + base * CS[k], tS * CS[k])
+        bimg.linear(("gH",), zp["gH"], tS * R * d * 4)
+        bimg.linear(("gsens",), zp["gsens"], tS * 2 * d * 4)
         for k in rows:
-            bimg.linear((k,), zp[k], zf[k] * 4)
+            bimg.linear((k,), zp[k], tS * zf[k] * 4)
         for k, fld in (("g", "tape_g"), ("x", "tape_x"), ("o", "tape_o")):
-            bimg.linear((fld,), TB[k][0] + t0 * TB[k][1], TB[k][1])
+            bimg.linear((fld,), TB[k][0] + t0 * TB[k][1], tS * TB[k][1])
         b_rows = bimg.images(range(K))
         b_ref = ctypes.byref(b)
         p_bwd, r_bwd = L.ic_region_phase_bwd, L.ic_router_bwd
@@ -1313,17 +1690,19 @@ class LoopEngine:
             rb.f.H, rb.f.mask_prev = CP["H"] + base * CS["H"], CP["mask"] + base * CS["mask"]
             rb.src_off, rb.src_edges = tables["src_off"].data_ptr(), tables["src_edges"].data_ptr()
             rb.slab, rb.gHd, rb.slab_q = WP["rslab"], WP["gHd"], WP["slab_q"]
-            rb.gM, rb.gH, rb.sk = WP["gM"], zp["gH"], K
+            rb.gM, rb.gH, rb.sk = WP["gM"], zp["gH"], sS
             rimg = StructImage(rb)
             for k in (["msg", "keyv", "q", "wgt"] if prec else []):
-                rimg.linear(("f", k), CP[k] + base * CS[k], CS[k])
-            rimg.linear(("g_ebias_part",), zp["g_ebias_part"], Ez * 4)   # [ns, V, Ez] as the kernel sees it
+                rimg.linear(("f", k), CP[k] + base * CS[k], tS * CS[k])
+            # the kernel writes [ns, S*sk, Ez] partials per launch: interleaved over the steps when the loops sit
+            # K slots apart ([ns, V, Ez] in all), one [ns, S, Ez] block per step when they run in lockstep
+            rimg.linear(("g_ebias_part",), zp["g_ebias_part"], (ns * S * Ez if lock else Ez) * 4)
             if prec:
-                rimg.linear(("g_rawP_rows",), zp["g_rawP_rows"], Ez * d * 4)
+                rimg.linear(("g_rawP_rows",), zp["g_rawP_rows"], tS * Ez * d * 4)
             for k, fld in (("gmsg", "tape_gmsg"), ("H", "tape_H"), ("eact", "tape_eact"), ("gkey", "tape_gkey"),
                            ("gq", "tape_gq"), ("qact", "tape_qact")):
                 if k in RB:
-                    rimg.linear((fld,), RB[k][0] + rt0 * RB[k][1], RB[k][1])
+                    rimg.linear((fld,), RB[k][0] + rt0 * RB[k][1], tS * RB[k][1])
             rimg.linear(("in_slot",), in_slot.data_ptr(), S * 4)
             r_rows = rimg.images(range(K))
             rb_ref = ctypes.byref(rb)
@@ -1358,7 +1737,7 @@ class LoopEngine:
                 m._units[8:12] += torch.stack([torch.tensor(float(sum(r_live)), device=dev), ea.sum().float(), eany.sum(), dany.sum().float()])
         self._pass["blocks"].append((Z, V, s0))
         self._pass.setdefault("keep", []).append((sens, best, in_slot if E > 0 else None, mk))
-        return Z["gsens"].view(S, K * 2, d).sum(1)
+        return from_v(Z["gsens"]).reshape(S, K * 2, d).sum(1)
 
     # ------------------------------------------------------------------ per-pass reductions
     def _begin_pass(self) -> None:
@@ -1436,13 +1815,13 @@ class LoopBatchFn(torch.autograd.Function):
     def forward(ctx, sensors, anchor, engine, bt):
         ctx.engine, ctx.bt = engine, bt
         ctx.sshape = sensors.shape
-        return torch.stack([s.chunk.fields["H"][s.i0 + s.best] for s in bt["samples"]])
+        return torch.stack([s.chunk.fields["H"][s.i0 + s.best * s.ts] for s in bt["samples"]])
 
     @staticmethod
     def backward(ctx, gH):
         eng, bt = ctx.engine, ctx.bt
         gH = gH.contiguous()
-        if eng._batch_uniform(bt):
+        if bt.get("lockstep") or eng._batch_uniform(bt):
             eng.counters["batch_bwd"] += 1
             g = eng.backward_batch(bt, gH)
         else:

@@ -102,6 +102,12 @@ class CortexReasoner(FastAttrs, nn.Module):
         # True while a caller (train_step) promises not to back-propagate through the inner-step
         # logits / workspace: the loop then runs on the LoopEngine (engine.py)
         self._logits_detached = False
+        # "strict": reasoning_loop_batch runs the samples one after the other, region state carried from
+        # sample to sample -- the reference's schedule (model.py:462-503) and the mode every parity and
+        # headline number uses.  "multi": the samples are independent loops run in lockstep, every one
+        # from the state the bank holds when the call starts (SURVEY §7's multi-stream mode,
+        # LoopEngine.run_lockstep); each equals a batch-1 reasoning_loop from that state.
+        self.stream_mode = "strict"
         object.__setattr__(self, "engine", LoopEngine(self))
 
     # ------------------------------------------------------------------ plumbing
@@ -395,6 +401,52 @@ class CortexReasoner(FastAttrs, nn.Module):
         self.work.slots, reg_mask, H_cur = branches[best]
         return H_cur, reg_mask, last_logits, traces
 
+    def _reasoning_loop_batch_multi(self, K_inner: int, focus_batch: torch.Tensor, batched):
+        """stream_mode == "multi": all samples as independent lockstep loops.  Launch groups hold at
+        most 64 (loop, branch) streams; every loop of every group starts from the region state and
+        workspace the bank holds NOW, and the bank ends with the last loop's final state."""
+        eng = self.engine
+        vec, en, ent = batched
+        N, dev = vec.shape[0], vec.device
+        C = 1 if self.cfg.train_deterministic_inner_loop else max(1, self.cfg.B_br)
+        G = max(1, eng.MAX_LOCKSTEP_STREAMS // C)
+        if focus_batch.numel() > 0:
+            fo = focus_batch.reshape(N, -1).any(1).to(torch.uint8)
+        else:
+            fo = torch.ones(N, dtype=torch.uint8, device=dev)
+        aux = None
+        if self.verify is not None and getattr(self.verify, "aux_dim", 0) > 0:
+            aux = torch.zeros(N, 4, device=dev)
+            aux[:, 0] = en.detach()
+            if ent is not None:
+                aux[:, 2] = ent.detach().to(dev)
+        self.detach_state()
+        eng.resolve_pending()
+        b = self.bank
+        start = None
+        if N > G:  # later groups restart from the same state: keep a copy
+            start = {k: getattr(b, k).clone() for k in ("num", "den", "dt", "var", "surprise", "pred", "radius", "radius_var")}
+            start_slots = self.work.slots.clone()
+        self.router.begin_loop()
+        H_l, M_l, L_l, T_l = [], [], [], []
+        try:
+            for g0 in range(0, N, G):
+                g1 = min(N, g0 + G)
+                if start is not None and g0 > 0:
+                    for k, v in start.items():
+                        setattr(b, k, v)
+                    self.work.slots = start_slots
+                H, mk, lg, tr = eng.run_lockstep(K_inner, vec[g0:g1], fo[g0:g1], aux[g0:g1] if aux is not None else None)
+                H_l.append(H); M_l.append(mk); L_l.append(lg); T_l += tr
+        finally:
+            self.router.end_loop()
+        self.local_mix.last_energy = en[-1]
+        if ent is not None:
+            self.local_mix.attn.last_attn_entropy = ent[-1]
+        A = ent.detach().to(dev) if ent is not None else torch.zeros(N, device=dev)
+        cat = lambda l: l[0] if len(l) == 1 else torch.cat(l, 0)
+        return cat(H_l), cat(M_l).bool(), cat(L_l), T_l, en.detach(), A
+
     def reasoning_loop_batch(self, tokens_batch: torch.Tensor, K_inner: int, focus_batch: torch.Tensor):
         """Sequential over the batch, region fast-weight state carried from one sample to the
         next (detached), exactly as the reference (model.py:462-503)."""
@@ -405,6 +457,10 @@ class CortexReasoner(FastAttrs, nn.Module):
         if N > 1 and tokens_batch.is_cuda and not self.cfg.ff_dropout and not self.cfg.profile:
             batched = self.sensor_vectors_batch(tokens_batch, focus_batch)  # the loops only differ in region state
         eng = self.engine
+        if self.stream_mode not in ("strict", "multi"):
+            raise ValueError(f"stream_mode={self.stream_mode!r} (need 'strict' or 'multi')")
+        if self.stream_mode == "multi" and batched is not None and eng.lockstep_usable(dev, N):
+            return self._reasoning_loop_batch_multi(K_inner, focus_batch, batched)
         try:
             H_zero, mask_zero = self.zeros_state(dev)  # never written to: shared by all loops
             self._zero_H = H_zero
