@@ -23,6 +23,9 @@ m.sensor_vector = timed("sensor_vector(mixer fwd)", m.sensor_vector)
 m.engine._drive = timed("engine._drive(loop fwd)", m.engine._drive)
 m.engine.backward = timed("engine.backward(loop bwd)", m.engine.backward)
 m.engine.run = timed("engine.run(total)", m.engine.run)
+m.engine.run_lockstep = timed("engine.run_lockstep(multi-stream fwd)", m.engine.run_lockstep)
+if len(sys.argv) > 2:
+    m.stream_mode = sys.argv[2]  # strict | multi
 T.make_negatives = timed("make_negatives", T.make_negatives)
 opt.step = timed("opt.step", opt.step)
 orig_bwd = torch.Tensor.backward
