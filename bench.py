@@ -285,14 +285,15 @@ def main():
             lrb = max(1.0, units["bwd_router_launches"])
             prec = bool(cfg.enable_precision_routed_messages)
             fwd = dict(S=nb, R=cfg.R, n_f=units["region_steps"] / lf, u_f=units["fwd_unique_regions"] / lf,
-                       e=units["active_edges"] / lf, ep=units["active_edges"] / lf, q=units["dst_regions"] / lf,
+                       e=units["fwd_unique_edges"] / lf, ep=units["active_edges"] / lf, q=units["fwd_unique_dst"] / lf,
                        afd=cfg.enable_adaptive_filter_dynamics, prec=prec,
                        routed=bool(prec and cfg.d <= 256 and not cfg.train_deterministic_inner_loop
                                    and cfg.B_br > 1 and os.environ.get("IC_FUSE_STEP", "1") != "0"),
                        e_f=units["active_edges"] / lf, q_f=units["dst_regions"] / lf)
             bwd = dict(S=2 * B, R=cfg.R, n_b=units["bwd_pairs"] / lb, u_b=units["bwd_unique_regions"] / lb,
                        e=units["bwd_unique_edges"] / lrb, ep=units["bwd_edge_pairs"] / lrb, q=units["bwd_dst_regions"] / lrb,
-                       afd=cfg.enable_adaptive_filter_dynamics, prec=prec, rows=2 * B * cfg.R, e_upd=model.router.E)
+                       afd=cfg.enable_adaptive_filter_dynamics, prec=prec, rows=2 * B * cfg.R,
+                       e_upd=units["hebbian_edges"] / max(1.0, units["hebbian_launches"]))
 
             def bytes_per_launch(name, libb):
                 """algorithmic bytes of one launch of `name`: the library's own count for shape-determined kernels

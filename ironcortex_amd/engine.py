@@ -608,6 +608,9 @@ class LoopEngine:
             grp = masks.view(-1, nb, m.R) if len(steps) % nb == 0 else masks.view(-1, 1, m.R)
             m._units[:5] += torch.stack([masks.sum(), ea.sum(), (into > 0).sum().float(),
                                          torch.tensor(float(grp.shape[0]), device=dev), grp.amax(1).sum()])
+            eg = (ea.view(-1, nb, ea.shape[1]) if len(steps) % nb == 0 else ea.view(-1, 1, ea.shape[1])).amax(1)  # [launches,E]
+            dg = torch.zeros(eg.shape[0], m.R, device=dev).index_add_(1, m.router.dst_idx, eg)
+            m._units[12:14] += torch.stack([eg.sum(), (dg > 0).sum().float()])
 
     # ------------------------------------------------------------------ loop heads (HIP, no autograd)
     def _heads_setup(self, dev, nb: Optional[int] = None, lock: bool = False):

@@ -133,19 +133,24 @@ class CortexReasoner(FastAttrs, nn.Module):
     def count_units(self, on: bool) -> None:
         """Count region steps / active edges on the device (no sync) for throughput reports."""
         dev = self.reg_coords.device
-        self._units = torch.zeros(12, device=dev) if on else None
+        self._units = torch.zeros(16, device=dev) if on else None
         self.counters["inner_steps"] = 0
 
     def read_units(self) -> Dict[str, float]:
         self.engine.flush_units()
-        u = self._units.tolist() if self._units is not None else [0.0] * 12
+        u = self._units.tolist() if self._units is not None else [0.0] * 16
         # region-phase launches and, per launch, the (stream, region) pairs served and the distinct
         # regions among them (their weights are read once per launch): forward / backward
         return {"inner_steps": self.counters["inner_steps"], "region_steps": u[0], "active_edges": u[1],
                 "dst_regions": u[2], "fwd_region_launches": u[3], "fwd_unique_regions": u[4],
                 "bwd_region_launches": u[5], "bwd_pairs": u[6], "bwd_unique_regions": u[7],
                 # router backward launches: (stream, edge) pairs, distinct edges, distinct destinations
-                "bwd_router_launches": u[8], "bwd_edge_pairs": u[9], "bwd_unique_edges": u[10], "bwd_dst_regions": u[11]}
+                "bwd_router_launches": u[8], "bwd_edge_pairs": u[9], "bwd_unique_edges": u[10], "bwd_dst_regions": u[11],
+                # forward router launches (the branches of an outer iteration share one): distinct active edges /
+                # destinations per launch (an edge's matrices are read once for all its streams)
+                "fwd_unique_edges": u[12], "fwd_unique_dst": u[13],
+                # Hebbian nudge launches and the edge matrices they update (coefficient non-zero)
+                "hebbian_launches": u[14], "hebbian_edges": u[15]}
 
     def detach_state(self) -> None:
         if hasattr(self, "work") and self.work.slots.requires_grad:
@@ -264,6 +269,7 @@ class CortexReasoner(FastAttrs, nn.Module):
             into = torch.zeros(self.R, device=dev).index_add_(0, self.router.dst_idx, ea)
             n_act = mask.sum().float()
             self._units[:5] += torch.stack([n_act, ea.sum(), (into > 0).sum().float(), torch.ones_like(n_act), n_act])
+            self._units[12:14] += torch.stack([ea.sum(), (into > 0).sum().float()])
         # 4) heads on motor & workspace -- no host sync: the active set stays on the device
         logits, rtd_logits, ws_state, motor_state = self._heads(H_cur, mask[0])
         return H_cur, mask[0].bool(), logits, rtd_logits, ws_state, motor_state

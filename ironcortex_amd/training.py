@@ -221,6 +221,8 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
                     Hh, mp = dp.gather(Hh), dp.gather(mp)
                 coef = (1e-3 * gains.clamp_min(0.0))[router.dst_idx].unsqueeze(0) * mp[:, router.dst_idx] * mp[:, router.src_idx]
                 ops.hebbian_rank1(router._flat.stacked("W"), t["dst_of_edge"], t["src"], t["widx"], coef, Hh)
+                if model._units is not None:  # bench.py's device-side unit counters: edges this launch updates
+                    model._units[14:16] += torch.stack([torch.ones((), device=coef.device), (coef != 0).any(0).sum().float()])
         active_frac = mask_n.float().mean()
         fired = mask_n.any(dim=0)
         model.gate.update_homeo(dp.any(fired) if dp is not None else fired)
