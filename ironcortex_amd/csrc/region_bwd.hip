@@ -561,6 +561,273 @@ __global__ __launch_bounds__(256) void k_region_rkv_bwd(ic_region_bwd_args b, in
   }
 }
 
+// ---------------------------------------------------------------- split backward (default)
+// The r/k/v backward as TWO launches: the per-channel state / WKV / AFD backward is elementwise over
+// the active rows (k_region_chan_bwd: one wave per (stream, region) row, float4 lanes, every operand
+// row requested in one batch), and the transposed products W_{r,k,v}^T g are a pure weight-streaming
+// kernel (k_region_rkvT_bwd) that carries nothing but the weights, the accumulators of a batch of
+// streams and their 3*RPW gradient scalars: 236 -> ~130 VGPRs, no dependent load after the weights,
+// one LDS hand-over (two barriers) per batch of NSB streams instead of per stream, every wave
+// reducing one stream of the batch.  Same arithmetic, same order of additions as k_region_rkv_bwd.
+// value of lane `l` (a compile-time constant after unrolling) in every lane: v_readlane_b32 into a
+// scalar register -- no LDS crossbar trip, no vector register for the broadcast
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+struct ChanOut {
+  float gnum, gden, gvar, g_pn, g_on, g_rd, g_rpre, g_k, g_v;
+};
+
+__device__ __forceinline__ ChanOut chan_bwd_one(bool afd, float steps, float rd, float pn_p, float on_p,
+                                                float num_in, float den_in, float rr, float kk, float vv,
+                                                float gno, float gdo, float var_in, float gvo, float gy) {
+  ChanOut o;
+  const float rate = -ic_softplus(rd);
+  const float ex = expf(rate * steps);
+  const float lam = fmaxf(ex, IC_EPS_DIV);
+  const float numd = num_in * lam, dend = den_in * lam;
+  const float w = expf(fminf(kk, IC_MAX_EXP));
+  float g_r, g_v, g_w, g_numd, g_dend, g_lam, g_k_extra = 0.f, g_var_in = 0.f;
+  float g_pn_p = 0.f, g_on_p = 0.f;
+  if (afd) {
+    const float pn = ic_noise(pn_p), on = ic_noise(on_p);
+    const float vard = var_in * (lam * lam) + pn * steps;
+    const float dpe = dend + IC_EPS_DIV;
+    const float prd = numd / dpe;
+    const float resid = w * vv - prd;
+    const float e = expf(fminf(-kk, IC_MAX_EXP));
+    const float obs = e * on + IC_EPS_DIV;
+    const float T = vard + obs;
+    const float graw = vard / T;
+    const float gain = fminf(fmaxf(graw, IC_EPS_DIV), 1.0f);
+    const float st = prd + gain * resid;
+    const float den_n = dend + w;
+    g_r = gy * st;
+    const float g_st = gy * rr + gno * den_n;
+    const float g_den_n = gno * st + gdo;
+    g_dend = g_den_n;
+    g_w = g_den_n;
+    const float g_gain = g_st * resid - gvo * vard;
+    const float g_resid = g_st * gain;
+    float g_vard = gvo * (1.0f - gain);
+    const float g_graw = (graw >= IC_EPS_DIV && graw <= 1.0f) ? g_gain : 0.f;
+    g_vard += g_graw * obs / (T * T);
+    const float g_obs = -g_graw * vard / (T * T);
+    const float g_prd = g_st - g_resid;
+    g_w += g_resid * vv;
+    g_v = g_resid * w;
+    g_numd = g_prd / dpe;
+    g_dend += -g_prd * prd / dpe;
+    const float g_e = g_obs * on;
+    g_on_p = g_obs * e * ic_noise_grad(on_p);
+    g_k_extra = (-kk <= IC_MAX_EXP) ? -g_e * e : 0.f;
+    g_var_in = g_vard * (lam * lam);
+    g_lam = g_numd * num_in + g_dend * den_in + g_vard * var_in * 2.0f * lam;
+    g_pn_p = g_vard * steps * ic_noise_grad(pn_p);
+  } else {
+    const float num_n = numd + w * vv, den_n = dend + w;
+    const float dpe = den_n + IC_EPS_DIV;
+    const float q = num_n / dpe;
+    g_r = gy * q;
+    const float g_q = gy * rr;
+    g_numd = gno + g_q / dpe;
+    g_dend = gdo - g_q * q / dpe;
+    g_v = g_numd * w;
+    g_w = g_numd * vv + g_dend;
+    g_lam = g_numd * num_in + g_dend * den_in;
+  }
+  o.g_k = ((kk <= IC_MAX_EXP) ? g_w * w : 0.f) + g_k_extra;
+  const float g_rate = (ex >= IC_EPS_DIV) ? g_lam * lam * steps : 0.f;
+  o.g_rd = -g_rate * ic_softplus_grad(rd);
+  o.g_rpre = g_r * rr * (1.0f - rr);
+  o.g_v = g_v;
+  o.gnum = g_numd * lam;
+  o.gden = g_dend * lam;
+  o.gvar = g_var_in;
+  o.g_pn = g_pn_p;
+  o.g_on = g_on_p;
+  return o;
+}
+
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_chan_bwd(ic_region_bwd_args b, int nslab) {
+  const ic_region_args& a = b.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int s, r, row;
+  if (!spread_row(b, blockIdx.x * 4 + wave, s, r, row)) return;
+  if (!a.mask[row]) return;
+  const int d = a.d;
+  const int SR = a.S * stream_step(b) * a.R;
+  const size_t off = (size_t)row * d;
+  const bool afd = a.flags & IC_F_AFD, vec = a.flags & IC_F_NOISE_VEC, rt = a.flags & IC_F_RT;
+  RowFrag<DCH> num, den, rs, ks, vs, gno, gdo, var, gvo, rdv, pnv, onv, gy;
+  load_row(num, a.num + off, d, lane);
+  load_row(den, a.den + off, d, lane);
+  load_row(rs, a.r_s + off, d, lane);
+  load_row(ks, a.k_s + off, d, lane);
+  load_row(vs, a.v_s + off, d, lane);
+  load_opt(gno, b.gnum_o, off, d, lane);
+  load_opt(gdo, b.gden_o, off, d, lane);
+  load_row(rdv, a.raw_decay + (size_t)r * d, d, lane);
+  zero_frag(var); zero_frag(gvo); zero_frag(pnv); zero_frag(onv);
+  float pn_s = 0.f, on_s = 0.f;
+  if (afd) {
+    load_row(var, a.var + off, d, lane);
+    load_opt(gvo, b.gvar_o, off, d, lane);
+    if (vec) {
+      load_row(pnv, a.pn_param + (size_t)r * d, d, lane);
+      load_row(onv, a.on_param + (size_t)r * d, d, lane);
+    } else {
+      pn_s = a.pn_param[r];
+      on_s = a.on_param[r];
+    }
+  }
+  const float steps = (float)(a.dt[row] + 1);
+  // gy: the o-projection's slabs, reduced here (radial-tangential: plus its scalar chain)
+  if (rt) {
+    rt_gy_row<DCH>(b, gy, row, r, nslab, lane, true);
+  } else {
+    zero_frag(gy);
+    sum_slabs(gy, b.slab + off, (size_t)SR * d, nslab, d, lane);
+  }
+  RowFrag<DCH> o_num, o_den, o_var, o_pn, o_on, o_rd, t_r, t_k, t_v;
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    const int ch0 = 256 * j + 4 * lane;
+#define IC_CH(c) chan_bwd_one(afd, steps, rdv.v[j].c, vec ? pnv.v[j].c : pn_s, vec ? onv.v[j].c : on_s, num.v[j].c, \
+                              den.v[j].c, rs.v[j].c, ks.v[j].c, vs.v[j].c, gno.v[j].c, gdo.v[j].c, var.v[j].c,      \
+                              gvo.v[j].c, gy.v[j].c)
+    const ChanOut c0 = IC_CH(x), c1 = IC_CH(y), c2 = IC_CH(z), c3 = IC_CH(w);
+#undef IC_CH
+    o_num.v[j] = make_float4(c0.gnum, c1.gnum, c2.gnum, c3.gnum);
+    o_den.v[j] = make_float4(c0.gden, c1.gden, c2.gden, c3.gden);
+    o_var.v[j] = make_float4(c0.gvar, c1.gvar, c2.gvar, c3.gvar);
+    o_pn.v[j] = make_float4(c0.g_pn, c1.g_pn, c2.g_pn, c3.g_pn);
+    o_on.v[j] = make_float4(c0.g_on, c1.g_on, c2.g_on, c3.g_on);
+    o_rd.v[j] = make_float4(c0.g_rd, c1.g_rd, c2.g_rd, c3.g_rd);
+    t_r.v[j] = make_float4(c0.g_rpre, c1.g_rpre, c2.g_rpre, c3.g_rpre);
+    t_k.v[j] = make_float4(c0.g_k, c1.g_k, c2.g_k, c3.g_k);
+    // rotation backward (iron_rope.py:63-64): channels (2p, 2p+1) rotate together by step_pos * W_time[p]
+    float v0 = c0.g_v, v1 = c1.g_v, v2 = c2.g_v, v3 = c3.g_v;
+    if (ch0 < 2 * a.m_time) {
+      const float th = a.step_pos * a.W_time[ch0 >> 1];
+      const float c = cosf(th), sn = sinf(th);
+      const float e = c0.g_v * c + c1.g_v * sn, o = -c0.g_v * sn + c1.g_v * c;
+      v0 = e; v1 = o;
+    }
+    if (ch0 + 2 < 2 * a.m_time) {
+      const float th = a.step_pos * a.W_time[(ch0 >> 1) + 1];
+      const float c = cosf(th), sn = sinf(th);
+      const float e = c2.g_v * c + c3.g_v * sn, o = -c2.g_v * sn + c3.g_v * c;
+      v2 = e; v3 = o;
+    }
+    t_v.v[j] = make_float4(v0, v1, v2, v3);
+  }
+  store_row(o_num, b.gnum + off, d, lane);
+  store_row(o_den, b.gden + off, d, lane);
+  if (afd) {
+    store_row(o_var, b.gvar + off, d, lane);
+    store_row(o_pn, b.g_pn_rows + off, d, lane);
+    store_row(o_on, b.g_on_rows + off, d, lane);
+  }
+  store_row(o_rd, b.g_raw_decay_rows + off, d, lane);
+  float* tg = b.tape_g + (size_t)row * 4 * d;
+  store_row(t_r, tg, d, lane);
+  store_row(t_k, tg + d, d, lane);
+  store_row(t_v, tg + 2 * d, d, lane);
+}
+
+// The batch hand-over shared by the two transposed-product kernels: every wave leaves its partial
+// rows of the batch's streams in LDS, wave u sums stream u's four partials in wave order.
+template <int DCH, int NSB>
+struct BatchRed {
+  float v[4][NSB][DCH * 256];
+};
+
+template <int DCH, int RPW, int NSB>
+__global__ __launch_bounds__(256) void k_region_rkvT_bwd(ic_region_bwd_args b) {
+  const ic_region_args& a = b.f;
+  const int r = blockIdx.y;
+  const int sk = stream_step(b);
+  __shared__ BatchRed<DCH, NSB> red;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * (4 * RPW) + wave * RPW;
+  const size_t dd = (size_t)d * d;
+  const int SR = a.S * sk * a.R;
+  const int nz = gridDim.z;
+  RowFrag<DCH> wr[RPW], wk[RPW], wv[RPW];
+  bool loaded = false;
+  // lane l < 3*RPW fetches gradient scalar (matrix l / RPW, row row0 + l % RPW) of a stream
+  const int zm = lane / RPW, zq = lane % RPW;
+  const bool zvalid = lane < 3 * RPW && row0 + zq < d;
+  for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+    const int sl = sc + lane * nz;
+    unsigned long long act = __ballot(sl < a.S && a.mask[(size_t)sl * sk * a.R + r] != 0);
+    if (!act) continue;
+    if (!loaded) {  // (wave-uniform) the weights are only requested once the region is known to have work
+      const float* Wr = a.W + (size_t)r * 4 * dd;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        if (row0 + i < d) {
+          load_row(wr[i], Wr + (size_t)(row0 + i) * d, d, lane);
+          load_row(wk[i], Wr + dd + (size_t)(row0 + i) * d, d, lane);
+          load_row(wv[i], Wr + 2 * dd + (size_t)(row0 + i) * d, d, lane);
+        } else {
+          zero_frag(wr[i]); zero_frag(wk[i]); zero_frag(wv[i]);
+        }
+      }
+      loaded = true;
+    }
+    while (act) {
+      int srow[NSB];
+      float z[NSB];
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) {
+        srow[u] = -1;
+        z[u] = 0.f;
+        if (act) {
+          const int s = sc + (__ffsll((long long)act) - 1) * nz;
+          act &= act - 1;
+          srow[u] = s * sk * a.R + r;
+          if (zvalid) z[u] = b.tape_g[((size_t)srow[u] * 4 + zm) * d + row0 + zq];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) {
+        if (srow[u] < 0) continue;  // wave-uniform
+        RowFrag<DCH> acc;
+        zero_frag(acc);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          axpy_frag(acc, lane_bcast(z[u], q), wr[q]);
+          axpy_frag(acc, lane_bcast(z[u], RPW + q), wk[q]);
+          axpy_frag(acc, lane_bcast(z[u], 2 * RPW + q), wv[q]);
+        }
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) *reinterpret_cast<float4*>(&red.v[wave][u][256 * j + 4 * lane]) = acc.v[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) {
+        if (srow[u] < 0 || (u & 3) != wave) continue;
+        RowFrag<DCH> tot;
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          const int c = 256 * j + 4 * lane;
+          const float4 p0 = *reinterpret_cast<const float4*>(&red.v[0][u][c]), p1 = *reinterpret_cast<const float4*>(&red.v[1][u][c]);
+          const float4 p2 = *reinterpret_cast<const float4*>(&red.v[2][u][c]), p3 = *reinterpret_cast<const float4*>(&red.v[3][u][c]);
+          tot.v[j] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y),
+                                 (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+        }
+        store_row(tot, b.slab2 + ((size_t)blockIdx.x * SR + srow[u]) * d, d, lane);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------- prologue backward
 template <int DCH>
 __global__ __launch_bounds__(256) void k_region_pro_bwd(ic_region_bwd_args b, int nslab, int fold,
@@ -749,21 +1016,32 @@ extern "C" int ic_region_phase_bwd(const ic_region_bwd_args* b, ic_stream_t stre
   const float oma = (float)(1.0 - a->pred_alpha);
   const bool soft = (a->flags & IC_F_KWTA_SOFT) && !(a->flags & IC_F_NOKWTA) && a->kwta_k > 0;
   const int fold = soft ? 0 : 1;
-#define IC_REGION_BWD(DCH_, RPW_)                                                                                            \
+#define IC_REGION_BWD(DCH_, RPW_, NSB_)                                                                                      \
   do {                                                                                                                       \
     constexpr int DCH = DCH_;                                                                                                \
     if (!fold)                                                                                                               \
       IC_TIMED(IC_KID_region_fin_bwd, st, hipLaunchKernelGGL(k_region_fin_bwd<DCH>, grow, blk, 0, st, *b, oma));             \
     IC_TIMED(IC_KID_region_out_bwd, st, hipLaunchKernelGGL((k_region_out_bwd<DCH, RPW_>), gmat, blk, 0, st, *b, fold));      \
-    IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, RPW_>), gmat, blk, 0, st, *b, nslab));     \
+    if (split) {                                                                                                             \
+      IC_TIMED(IC_KID_region_mid_bwd, st, hipLaunchKernelGGL(k_region_chan_bwd<DCH>, grow, blk, 0, st, *b, nslab));          \
+      IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkvT_bwd<DCH, RPW_, NSB_>), gmat, blk, 0, st, *b));   \
+    } else {                                                                                                                 \
+      IC_TIMED(IC_KID_region_rkv_bwd, st, hipLaunchKernelGGL((k_region_rkv_bwd<DCH, RPW_>), gmat, blk, 0, st, *b, nslab));   \
+    }                                                                                                                        \
     IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab, fold, oma));  \
   } while (0)
+  // The r/k/v backward as one fused launch (few streams per region: launch-bound sizes, one launch less) or split
+  // into the per-channel kernel + the weight-streaming kernel (many streams per region: at R=512, k=32, S=64 the
+  // fused kernel walks ~4 streams per workgroup serially with 236 VGPRs, 162 us; split 25 + 106 us; at S=8 both
+  // take the same time).  IC_BWD_SPLIT=0/1 forces one of them (A/B timing; same results bit for bit).
+  static const int split_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool split = split_env >= 0 ? split_env == 1 : a->S / nz >= 32;
   if (a->d <= 256)
-    IC_REGION_BWD(1, 8);
+    IC_REGION_BWD(1, 8, 4);
   else if (a->d <= 512)
-    IC_REGION_BWD(2, 2);
+    IC_REGION_BWD(2, 2, 4);
   else
-    IC_REGION_BWD(4, 2);
+    IC_REGION_BWD(4, 2, 2);
 #undef IC_REGION_BWD
   IC_LAUNCH_CHECK("ic_region_phase_bwd");
   return IC_OK;

@@ -575,6 +575,135 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   }
 }
 
+// The same products for MANY streams per edge (S / gridDim.z >= 32): the streams are tested 64 at a time with
+// one ballot (k_router_mat_bwd asks for every stream's sender mask byte in turn: 64 dependent round trips
+// per workgroup at S = 64), the active ones go through in batches of NSB -- operands of the whole batch
+// requested together, one LDS hand-over (two barriers) per batch, wave u summing stream u's partials.
+// Same sums as k_router_mat_bwd up to fp32 rounding (the edge bias is applied to the finished partial row).
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <int DCH, int RPW, int NSB>
+__global__ __launch_bounds__(256) void k_router_matT_bwd(ic_router_bwd_args b) {
+  const ic_router_args& a = b.f;
+  __shared__ float red[4][NSB][DCH * 256];
+  __shared__ float red_b[4][NSB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * (4 * RPW) + wave * RPW;
+  const size_t dd = (size_t)d * d;
+  const bool prec = a.flags & IC_RF_PRECISION;
+  const int y = blockIdx.y;
+  const bool is_q = y >= a.E;
+  const int e = y, r = y - a.E;
+  const int src = is_q ? r : a.src[e];
+  const int sk = stream_step(b), nz = gridDim.z;
+  const float* W = is_q ? a.query_W + (size_t)r * dd : a.W + (size_t)a.widx[e] * dd;
+  const float* K = (!is_q && prec) ? a.key_W + (size_t)a.widx[e] * dd : nullptr;
+  const float bias = is_q ? 1.0f : a.ebias[e];
+  const int SE = a.S * sk * a.E, SR = a.S * sk * a.R;
+  const int ch = row0 + (lane < RPW ? lane : 0);
+  const bool gvalid = lane < RPW && ch < d;
+  RowFrag<DCH> w[RPW], kf[RPW];
+  bool loaded = false;
+  for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+    const int sl = sc + lane * nz;
+    unsigned long long act =
+        __ballot(sl < a.S && (is_q ? (b.tape_qact[(size_t)sl * sk * a.R + r] != 0) : prev_on(b, sl, src)));
+    if (!act) continue;
+    if (!loaded) {  // (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        if (row0 + i < d) {
+          load_row(w[i], W + (size_t)(row0 + i) * d, d, lane);
+          if (K) load_row(kf[i], K + (size_t)(row0 + i) * d, d, lane);
+          else zero_frag(kf[i]);
+        } else {
+          zero_frag(w[i]);
+          zero_frag(kf[i]);
+        }
+      }
+      loaded = true;
+    }
+    while (act) {
+      int sv[NSB];
+      float g[NSB], gk[NSB];
+      RowFrag<DCH> h[NSB];
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) {
+        sv[u] = -1;
+        g[u] = gk[u] = 0.f;
+        zero_frag(h[u]);
+        if (act) {
+          const int s = sc + (__ffsll((long long)act) - 1) * nz;
+          act &= act - 1;
+          sv[u] = s;
+          const int vs = s * sk;
+          const float* gvec = is_q ? b.tape_gq + ((size_t)vs * a.R + r) * d : b.tape_gmsg + ((size_t)vs * a.E + e) * d;
+          if (gvalid) {
+            g[u] = gvec[ch];
+            if (K) gk[u] = b.tape_gkey[((size_t)vs * a.E + e) * d + ch];
+          }
+          if (!is_q) load_row(h[u], h_row(b, s, src), d, lane);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) {
+        if (sv[u] < 0) continue;  // wave-uniform
+        // W^T g without the bias first: this workgroup's share of d/d ebias = sum_i g_i (W h)_i is the dot product of
+        // that partial row with h -- ONE wave reduction per stream instead of one per weight row
+        RowFrag<DCH> acc, acck;
+        zero_frag(acc);
+        zero_frag(acck);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          if (row0 + i < d) {  // wave-uniform
+            axpy_frag(acc, lane_bcast(g[u], i), w[i]);
+            if (K) axpy_frag(acck, lane_bcast(gk[u], i), kf[i]);
+          }
+        }
+        float part_b = 0.f;
+        if (!is_q) {
+          part_b = wave_sum(dot_frag(acc, h[u]));
+#pragma unroll
+          for (int j = 0; j < DCH; ++j) {
+            acc.v[j].x = fmaf(bias, acc.v[j].x, acck.v[j].x); acc.v[j].y = fmaf(bias, acc.v[j].y, acck.v[j].y);
+            acc.v[j].z = fmaf(bias, acc.v[j].z, acck.v[j].z); acc.v[j].w = fmaf(bias, acc.v[j].w, acck.v[j].w);
+          }
+        }
+        if (!is_q && gvalid) b.tape_gmsg[((size_t)sv[u] * sk * a.E + e) * d + ch] = g[u] * bias;  // fold ebias into the tape entry
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) *reinterpret_cast<float4*>(&red[wave][u][256 * j + 4 * lane]) = acc.v[j];
+        if (lane == 0) red_b[wave][u] = part_b;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) {
+        if (sv[u] < 0 || (u & 3) != wave) continue;
+        RowFrag<DCH> tot;
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) {
+          const int c = 256 * j + 4 * lane;
+          const float4 p0 = *reinterpret_cast<const float4*>(&red[0][u][c]), p1 = *reinterpret_cast<const float4*>(&red[1][u][c]);
+          const float4 p2 = *reinterpret_cast<const float4*>(&red[2][u][c]), p3 = *reinterpret_cast<const float4*>(&red[3][u][c]);
+          tot.v[j] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y),
+                                 (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+        }
+        const int vs = sv[u] * sk;
+        if (is_q) {
+          store_row(tot, b.slab_q + ((size_t)blockIdx.x * SR + vs * a.R + r) * d, d, lane);
+        } else {
+          store_row(tot, b.slab + ((size_t)blockIdx.x * SE + vs * a.E + e) * d, d, lane);
+          if (lane == 0)
+            b.g_ebias_part[(size_t)blockIdx.x * SE + vs * a.E + e] = (red_b[0][u] + red_b[1][u]) + (red_b[2][u] + red_b[3][u]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------- backward: gather per sender
 template <int DCH>
 __global__ __launch_bounds__(256) void k_router_gather_bwd(ic_router_bwd_args b, int nslab) {
@@ -806,20 +935,26 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
   const int ny = a->E + ((a->flags & IC_RF_PRECISION) ? a->R : 0);
   int nz = 1;
   while (nz < a->S && nz < 16 && nslab * ny * nz < 512) nz *= 2;
+  // many streams per workgroup: the batched variant of the transposed products (IC_BWD_SPLIT=0/1 forces one)
+  static const int many_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool many = many_env >= 0 ? many_env == 1 : a->S / nz >= 32;
   if (a->d <= 256) {
     constexpr int DCH = 1;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
-    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny, nz), blk, 0, st, *b));
+    if (ny > 0 && many) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 8, 4>), dim3(nslab, ny, nz), blk, 0, st, *b));
+    else if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else if (a->d <= 512) {
     constexpr int DCH = 2;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b));
-    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
+    if (ny > 0 && many) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 2, 4>), dim3(nslab, ny, nz), blk, 0, st, *b));
+    else if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else {
     constexpr int DCH = 4;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b));
-    if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
+    if (ny > 0 && many) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 2, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
+    else if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   }
   IC_LAUNCH_CHECK("ic_router_bwd");

@@ -60,6 +60,8 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
                 bank.dt = torch.randint(0, 8, (S, R), dtype=torch.int32, device=dev)
                 state0 = (bank.num, bank.den, bank.pred, bank.dt)
 
+                flush = torch.zeros(1 << 28, device=dev) if os.environ.get("IC_SWEEP_FLUSH") == "1" else None
+
                 def run(grad, i=0):
                     mask, H = masks[i % len(masks)], Hs[i % len(masks)]
                     bank.num, bank.den, bank.pred, bank.dt = state0
@@ -67,13 +69,19 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
                         Hg = H.clone().requires_grad_(True)
                         M = router.route(Hg, mask, coords)
                         out = bank.phase(M, sensor, nin, mask, 0.5)
-                        (out.sum() + bank.num.sum()).backward()
+                        loss = out.sum() + bank.num.sum()
+                        if flush is not None:  # IC_SWEEP_FLUSH=1: stream 1 GiB through the caches between forward and backward
+                            flush.sum()
+                        loss.backward()
                         for p in list(router.parameters()) + [p for c in cells for p in c.parameters()]:
                             p.grad = None
                     else:
                         with torch.no_grad():
                             M = router.route(H, mask, coords)
                             bank.phase(M, sensor, nin, mask, 0.5)
+                            for _ in range(int(os.environ.get("IC_SWEEP_REPEAT", "0"))):  # same weights again, ~100 us later
+                                bank.num, bank.den, bank.pred, bank.dt = state0
+                                bank.phase(M, sensor, nin, mask, 0.5)
 
                 for i in range(3):
                     run(backward, i)
