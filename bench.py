@@ -78,6 +78,9 @@ def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
         "region_out_bwd": u_b * dd + n_b * 4 * vec,
         "region_rkv_bwd": u_b * 3 * dd + n_b * (16 + (6 if afd else 0)) * vec,
         "region_pro_bwd": n_b * 10 * vec,
+        # split r/k/v backward (many streams per workgroup): per active pair 8 state / activation / incoming-gradient
+        # rows + the o-projection's 8 slab rows in, 3 tape rows + 3 gradient rows out (+5 under AFD)
+        "region_mid_bwd": n_b * (22 + (5 if afd else 0)) * vec,
         "region_fin_bwd": n_b * 4 * vec,
         "wgrad_region": u_b * 4 * dd * 2 + n_b * 6 * vec,               # dW read-modify-write once per touched region + tape
         # router

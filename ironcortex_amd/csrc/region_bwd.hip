@@ -1032,10 +1032,11 @@ extern "C" int ic_region_phase_bwd(const ic_region_bwd_args* b, ic_stream_t stre
   } while (0)
   // The r/k/v backward as one fused launch (few streams per region: launch-bound sizes, one launch less) or split
   // into the per-channel kernel + the weight-streaming kernel (many streams per region: at R=512, k=32, S=64 the
-  // fused kernel walks ~4 streams per workgroup serially with 236 VGPRs, 162 us; split 25 + 106 us; at S=8 both
-  // take the same time).  IC_BWD_SPLIT=0/1 forces one of them (A/B timing; same results bit for bit).
+  // fused kernel walks ~4 streams per workgroup serially with 236 VGPRs, 162 us; split 25 + 106 us; at S=8, from
+  // clean caches, fused 51 us, split 12 + 36 us).  Bandwidth-bound sizes take the split, launch-bound ones the fused
+  // kernel.  IC_BWD_SPLIT=0/1 forces one of them (A/B timing; same results bit for bit).
   static const int split_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  const bool split = split_env >= 0 ? split_env == 1 : a->S / nz >= 32;
+  const bool split = split_env >= 0 ? split_env == 1 : (a->S / nz >= 32 || (a->S / nz >= 8 && (long)a->R * a->S >= 2048));
   if (a->d <= 256)
     IC_REGION_BWD(1, 8, 4);
   else if (a->d <= 512)

@@ -937,7 +937,7 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
   while (nz < a->S && nz < 16 && nslab * ny * nz < 512) nz *= 2;
   // many streams per workgroup: the batched variant of the transposed products (IC_BWD_SPLIT=0/1 forces one)
   static const int many_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  const bool many = many_env >= 0 ? many_env == 1 : a->S / nz >= 32;
+  const bool many = many_env >= 0 ? many_env == 1 : (a->S / nz >= 32 || (a->S / nz >= 8 && (long)a->E * a->S >= 2048));  // (S = 1: its 16 KB of LDS slow the drain of idle workgroups)
   if (a->d <= 256) {
     constexpr int DCH = 1;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));

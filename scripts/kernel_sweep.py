@@ -35,6 +35,34 @@ def mask_sets(S, R, k, rotate):
     return sets
 
 
+_FLUSH = {}
+
+
+def flush_before_backward(on: bool) -> None:
+    """The backward of this harness goes through the general autograd path, which writes ~40 MB of gradient
+    tensors and zero-filled row buffers right before every library launch sequence.  Those dirty lines are
+    written back while the first weight-streaming kernels read (measured at R=512, k=32, S=8: region_rkv_bwd
+    63.7 us with them, 35.5 us without; region_out_bwd 29 -> 20 us), which prices the harness, not the
+    kernel (the LoopEngine zero-fills one block per pass).  With the hook on, a 1 GiB read is queued before
+    each backward entry point: the dirty lines are written back during that read and the kernels start
+    from clean -- and certainly weight-free -- caches."""
+    from ironcortex_amd.hip import ops
+    if "orig" not in _FLUSH:
+        _FLUSH["orig"] = ops._call
+    if not on:
+        ops._call = _FLUSH["orig"]
+        return
+
+    def call(name, a, *rest, **kw):
+        if name in ("ic_region_phase_bwd", "ic_router_bwd", "ic_region_wgrad", "ic_router_wgrad"):
+            if "buf" not in _FLUSH:
+                _FLUSH["buf"] = torch.zeros(1 << 28, device="cuda")
+            _FLUSH["buf"].sum()
+        return _FLUSH["orig"](name, a, *rest, **kw)
+
+    ops._call = call
+
+
 def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
     """Yields one dict per (R, S, k) point.  events=False: no HIP-event bracketing (the run is being
     traced by rocprofv3 instead); the row then only carries the algorithmic bytes."""
@@ -60,8 +88,6 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
                 bank.dt = torch.randint(0, 8, (S, R), dtype=torch.int32, device=dev)
                 state0 = (bank.num, bank.den, bank.pred, bank.dt)
 
-                flush = torch.zeros(1 << 28, device=dev) if os.environ.get("IC_SWEEP_FLUSH") == "1" else None
-
                 def run(grad, i=0):
                     mask, H = masks[i % len(masks)], Hs[i % len(masks)]
                     bank.num, bank.den, bank.pred, bank.dt = state0
@@ -69,19 +95,13 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
                         Hg = H.clone().requires_grad_(True)
                         M = router.route(Hg, mask, coords)
                         out = bank.phase(M, sensor, nin, mask, 0.5)
-                        loss = out.sum() + bank.num.sum()
-                        if flush is not None:  # IC_SWEEP_FLUSH=1: stream 1 GiB through the caches between forward and backward
-                            flush.sum()
-                        loss.backward()
+                        (out.sum() + bank.num.sum()).backward()
                         for p in list(router.parameters()) + [p for c in cells for p in c.parameters()]:
                             p.grad = None
                     else:
                         with torch.no_grad():
                             M = router.route(H, mask, coords)
                             bank.phase(M, sensor, nin, mask, 0.5)
-                            for _ in range(int(os.environ.get("IC_SWEEP_REPEAT", "0"))):  # same weights again, ~100 us later
-                                bank.num, bank.den, bank.pred, bank.dt = state0
-                                bank.phase(M, sensor, nin, mask, 0.5)
 
                 for i in range(3):
                     run(backward, i)
@@ -121,7 +141,7 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
 
 
 SWEEP_KERNELS = ("region_pro", "region_rkv", "region_out", "region_fin", "router_fwd", "region_out_bwd", "region_rkv_bwd",
-                 "region_pro_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_region", "wgrad_edge")
+                 "region_mid_bwd", "region_pro_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_region", "wgrad_edge")
 
 
 def main():
@@ -134,7 +154,9 @@ def main():
     ap.add_argument("--backward", action="store_true")
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many disjoint active sets")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event bracketing (run under rocprofv3)")
+    ap.add_argument("--flush-bwd", action="store_true", help="1 GiB read before every backward entry point (see flush_before_backward)")
     args = ap.parse_args()
+    flush_before_backward(args.flush_bwd)
     for row in sweep(args.R, args.k, args.S, args.d, args.iters, args.backward, args.rotate, not args.no_events):
         print(json.dumps(row), flush=True)
 

@@ -18,8 +18,8 @@ trap "kill $HB 2>/dev/null" EXIT
 for S in $SL; do
   for DIR in fwd bwd; do
     if [ "$MODE" != both ] && [ "$MODE" != $DIR ]; then continue; fi
-    B=""; [ $DIR = bwd ] && B="--backward"
-    ARGS="$R/scripts/kernel_sweep.py --R $RR --k $K --S $S --rotate 16 --iters 32 --no-events $B"
+    B=""; FLUSH=""; [ $DIR = bwd ] && B="--backward" && FLUSH="${SWEEP_FLUSH---flush-bwd}"
+    ARGS="$R/scripts/kernel_sweep.py --R $RR --k $K --S $S --rotate 16 --iters 32 --no-events $B $FLUSH"
     P=/tmp/sp_${TAG}_S${S}_${DIR}
     rm -rf $P; mkdir -p $P
     echo "$(date +%T) S=$S $DIR: kernel-trace pass" >> $OUT/${TAG}_progress.log
