@@ -1030,13 +1030,13 @@ extern "C" int ic_region_phase_bwd(const ic_region_bwd_args* b, ic_stream_t stre
     }                                                                                                                        \
     IC_TIMED(IC_KID_region_pro_bwd, st, hipLaunchKernelGGL(k_region_pro_bwd<DCH>, grow, blk, 0, st, *b, nslab, fold, oma));  \
   } while (0)
-  // The r/k/v backward as one fused launch (few streams per region: launch-bound sizes, one launch less) or split
-  // into the per-channel kernel + the weight-streaming kernel (many streams per region: at R=512, k=32, S=64 the
-  // fused kernel walks ~4 streams per workgroup serially with 236 VGPRs, 162 us; split 25 + 106 us; at S=8, from
-  // clean caches, fused 51 us, split 12 + 36 us).  Bandwidth-bound sizes take the split, launch-bound ones the fused
-  // kernel.  IC_BWD_SPLIT=0/1 forces one of them (A/B timing; same results bit for bit).
-  static const int split_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  const bool split = split_env >= 0 ? split_env == 1 : (a->S / nz >= 32 || (a->S / nz >= 8 && (long)a->R * a->S >= 2048));
+  // The r/k/v backward as one fused launch (fewer than 8 streams: the replay of a single loop) or split into the
+  // per-channel kernel + the weight-streaming kernel.  Measured (profiles/r02b_*): R=512, k=32, S=64 fused 162 us,
+  // split 20 + 85 us; S=8 fused 51 us, split 10 + 34 us; the batched backward of the 10M bench (S=16, R=10,
+  // streams split over gridDim.z) fused 27 us, split 16 + 8 us.  IC_BWD_SPLIT=0/1 forces one of them (A/B timing;
+  // same results bit for bit).
+  static const int split_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return (e && e[0]) ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool split = split_env >= 0 ? split_env == 1 : a->S >= 8;
   if (a->d <= 256)
     IC_REGION_BWD(1, 8, 4);
   else if (a->d <= 512)

@@ -935,9 +935,10 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
   const int ny = a->E + ((a->flags & IC_RF_PRECISION) ? a->R : 0);
   int nz = 1;
   while (nz < a->S && nz < 16 && nslab * ny * nz < 512) nz *= 2;
-  // many streams per workgroup: the batched variant of the transposed products (IC_BWD_SPLIT=0/1 forces one)
-  static const int many_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  const bool many = many_env >= 0 ? many_env == 1 : (a->S / nz >= 32 || (a->S / nz >= 8 && (long)a->E * a->S >= 2048));  // (S = 1: its 16 KB of LDS slow the drain of idle workgroups)
+  // 8 streams or more: the batched variant of the transposed products (at S = 1 its 16 KB of LDS slow the drain of
+  // the idle workgroups: 56 vs 29 us at R=512; 10M bench, S=16: 17 vs 33 us).  IC_BWD_SPLIT=0/1 forces one.
+  static const int many_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return (e && e[0]) ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool many = many_env >= 0 ? many_env == 1 : a->S >= 8;
   if (a->d <= 256) {
     constexpr int DCH = 1;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
