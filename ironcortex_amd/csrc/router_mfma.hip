@@ -187,6 +187,152 @@ __global__ __launch_bounds__(256) void k_wgrad_shared_mfma(ic_wgrad_edge_args a)
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.touched[k] = 1;
 }
 
+// ---- the same GEMM over a COMPACTED pair list (ic_wgrad_edge_args.pair_ws)
+// k_wgrad_pairs: one workgroup per matrix k writes, in (slot, stream, edge) order, the ids ts*E + e of the pairs
+// that contribute (slot visited, edge active) to ws + 2*nW + T*S*(edges with widx < k); ws[k] = their number,
+// ws[nW + k] = where the list starts.  Two passes over the activity bytes (count, scan, fill), 16 waves.
+constexpr int kMaxTS = 4096;
+__global__ __launch_bounds__(1024) void k_wgrad_pairs(ic_wgrad_edge_args a) {
+  __shared__ uint16_t elist[4096];
+  __shared__ int cnt_ts[kMaxTS];
+  __shared__ int ecnt, ebelow;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.x, TS = a.T * a.S;
+  if (wave == 0) {
+    int cnt = 0, below = 0;
+    for (int base = 0; base < a.E; base += 64) {
+      const int e = base + lane;
+      const int w = e < a.E ? a.widx[e] : -1;
+      const unsigned long long b = __ballot(w == k);
+      if (w == k) elist[cnt + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)e;
+      cnt += __popcll(b);
+      below += __popcll(__ballot(w >= 0 && w < k));
+    }
+    if (lane == 0) { ecnt = cnt; ebelow = below; }
+  }
+  __syncthreads();
+  const int cnt = ecnt;
+  for (int ts = wave; ts < TS; ts += 16) {  // pass 1: contributing pairs per (slot, stream)
+    int n = 0;
+    if (a.visited[ts / a.S]) {
+      for (int i0 = 0; i0 < cnt; i0 += 64) {
+        const int i = i0 + lane;
+        n += __popcll(__ballot(i < cnt && a.tape_eact[(size_t)ts * a.E + elist[i < cnt ? i : 0]] != 0));
+      }
+    }
+    if (lane == 0) cnt_ts[ts] = n;
+  }
+  __syncthreads();
+  if (wave == 0) {  // exclusive scan over ts (wave-wide shuffles, 64 at a time)
+    int carry = 0;
+    for (int t0 = 0; t0 < TS; t0 += 64) {
+      const int t = t0 + lane;
+      const int v = t < TS ? cnt_ts[t] : 0;
+      int inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+      }
+      if (t < TS) cnt_ts[t] = carry + inc - v;
+      carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+      a.pair_ws[k] = carry;
+      a.pair_ws[a.nW + k] = 2 * a.nW + TS * ebelow;
+    }
+  }
+  __syncthreads();
+  int* list = a.pair_ws + 2 * a.nW + (size_t)TS * ebelow;
+  for (int ts = wave; ts < TS; ts += 16) {  // pass 2: fill
+    if (!a.visited[ts / a.S]) continue;
+    int off = cnt_ts[ts];
+    for (int i0 = 0; i0 < cnt; i0 += 64) {
+      const int i = i0 + lane;
+      const int e = elist[i < cnt ? i : 0];
+      const bool on = i < cnt && a.tape_eact[(size_t)ts * a.E + e] != 0;
+      const unsigned long long b = __ballot(on);
+      if (on) list[off + __popcll(b & ((1ull << lane) - 1ull))] = ts * a.E + e;
+      off += __popcll(b);
+    }
+  }
+}
+
+// ks > 1: split-K -- workgroup (k, sp) walks the sp-th share of the list and stores its tile of partial sums
+// to part[k][sp] (plain stores, zeros for an empty share); k_wgrad_reduce adds the shares in order.
+__global__ __launch_bounds__(256) void k_wgrad_shared_mfma_list(ic_wgrad_edge_args a, int ks, float* part) {
+  __shared__ float As[kTM][kTK + 1];
+  __shared__ float Bs[kTK][kTN + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = a.d, k = blockIdx.z / ks, sp = blockIdx.z % ks;
+  const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * kTN;
+  const int Pall = a.pair_ws[k];
+  if (Pall == 0) return;
+  const int* list = a.pair_ws + a.pair_ws[a.nW + k];
+  const int cps = ((Pall + kTK - 1) / kTK + ks - 1) / ks;  // chunks per share
+  const int pb = sp * cps * kTK, P = min(Pall, pb + cps * kTK);
+  v16f acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  for (int p0 = pb; p0 < P; p0 += kTK) {
+    {  // A[i][p] = g[pair p][row0 + i]; thread -> (pair tid % 32, 16 rows)
+      const int pp = tid & 31, i0 = (tid >> 5) * 16;
+      const float* g = p0 + pp < P ? a.tape_g + (size_t)list[p0 + pp] * d : nullptr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = row0 + i0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g && i < d) v = *reinterpret_cast<const float4*>(g + i);
+        As[i0 + 4 * q + 0][pp] = v.x; As[i0 + 4 * q + 1][pp] = v.y; As[i0 + 4 * q + 2][pp] = v.z; As[i0 + 4 * q + 3][pp] = v.w;
+      }
+    }
+    {  // B[p][j] = H[pair p's sender][col0 + j]; thread -> (pair tid / 8, 4 columns)
+      const int pp = tid >> 3, js = (tid & 7) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + pp < P && col0 + js < d) {
+        const int id = list[p0 + pp], ts = id / a.E, e = id - ts * a.E;
+        v = *reinterpret_cast<const float4*>(a.tape_H + ((size_t)ts * a.R + a.src[e]) * d + col0 + js);
+      }
+      Bs[pp][js + 0] = v.x; Bs[pp][js + 1] = v.y; Bs[pp][js + 2] = v.z; Bs[pp][js + 3] = v.w;
+    }
+    __syncthreads();
+    mfma_chunk(As, Bs, wave, lane, acc);
+    __syncthreads();
+  }
+  const int j = col0 + (lane & 31);
+  if (j < d) {
+    float* out = ks > 1 ? part + ((size_t)k * ks + sp) * d * d : a.gW + (size_t)k * d * d;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int i = row0 + wave * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
+      if (i < d) {
+        if (ks > 1) out[(size_t)i * d + j] = acc[v];
+        else out[(size_t)i * d + j] += acc[v];
+      }
+    }
+  }
+  if (ks == 1 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.touched[k] = 1;
+}
+
+// gW[k] += part[k][0] + part[k][1] + ... (in that order); float4 per thread
+__global__ __launch_bounds__(256) void k_wgrad_reduce(ic_wgrad_edge_args a, int ks, const float* part) {
+  const int k = blockIdx.y;
+  if (a.pair_ws[k] == 0) return;
+  const size_t dd = (size_t)a.d * a.d, i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= dd) return;
+  const float* p = part + (size_t)k * ks * dd + i;
+  float4 t = *reinterpret_cast<const float4*>(p);
+  for (int sp = 1; sp < ks; ++sp) {
+    const float4 u = *reinterpret_cast<const float4*>(p + (size_t)sp * dd);
+    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+  }
+  float4* out = reinterpret_cast<float4*>(a.gW + (size_t)k * dd + i);
+  float4 o = *out;
+  o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+  *out = o;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.touched[k] = 1;
+}
+
 }  // namespace
 
 // library-internal launchers (router.hip: ic_router_fwd / ic_router_wgrad)
@@ -199,6 +345,20 @@ int ic_router_shared_fwd_launch(const ic_router_args* a, hipStream_t st) {
 
 int ic_wgrad_shared_launch(const ic_wgrad_edge_args* a, hipStream_t st) {
   const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->d, kTN), a->nW);
+  const long long TS = (long long)a->T * a->S;
+  if (a->pair_ws && TS <= kMaxTS && TS * a->E < (1ll << 31) && a->pair_ws_len >= 2ll * a->nW + TS * a->E) {
+    // split-K when the lists can be long and the workspace has room for the partial tiles (float, 256-byte aligned)
+    const long long list_len = (2ll * a->nW + TS * a->E + 63) / 64 * 64, dd = (long long)a->d * a->d;
+    int ks = 1;
+    if (TS * a->E / a->nW >= 1024 && a->d % 4 == 0)
+      for (ks = 8; ks > 1 && a->pair_ws_len < list_len + (long long)a->nW * ks * dd; ks /= 2) {}
+    float* part = reinterpret_cast<float*>(a->pair_ws + list_len);
+    IC_TIMED(IC_KID_wgrad_mfma, st, hipLaunchKernelGGL(k_wgrad_pairs, dim3(a->nW), dim3(1024), 0, st, *a));
+    IC_TIMED(IC_KID_wgrad_mfma, st, hipLaunchKernelGGL(k_wgrad_shared_mfma_list, dim3(grid.x, grid.y, a->nW * ks), dim3(256), 0, st, *a, ks, part));
+    if (ks > 1)
+      IC_TIMED(IC_KID_wgrad_mfma, st, hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((dd / 4 + 255) / 256), a->nW), dim3(256), 0, st, *a, ks, part));
+    return IC_OK;
+  }
   IC_TIMED(IC_KID_wgrad_mfma, st, hipLaunchKernelGGL(k_wgrad_shared_mfma, grid, dim3(256), 0, st, *a));
   return IC_OK;
 }

@@ -446,6 +446,10 @@ def router_wgrad(tape: Tape, spec: RouterSpec, tables: Dict[str, torch.Tensor], 
             dst_off=tables["dst_off"], src=tables["src"], widx=tables["widx"], tape_g=tape.buf[gname],
             tape_H=tape.buf["H"], tape_eact=tape.buf["qact" if which == 2 else "eact"], visited=tape.visited,
             gW=gW, touched=touched)
+    if which != 2 and spec.nW != spec.E:  # shared matrices: workspace for the compacted list of contributing pairs
+        n = (2 * spec.nW + tape.pos * S * spec.E + 63) // 64 * 64 + 8 * spec.nW * spec.d * spec.d  # list + split-K partial tiles
+        ws = torch.empty(n, dtype=torch.int32, device=gW.device)
+        a.pair_ws, a.pair_ws_len = ptr(ws), n
     _call("ic_router_wgrad", a)
 
 

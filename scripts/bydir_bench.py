@@ -63,8 +63,8 @@ def main():
         row = {"R": R, "S": S, "d": d, "active_fraction": args.p, "columns": n_cols, "active_edge_pairs": pairs,
                "fwd_GFLOP": flops_fwd / 1e9, "wgrad_GFLOP": flops_wgrad / 1e9, "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS, "kernels": {}}
         for name, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-            us = ms / n * 1e3
-            k = {"avg_us": round(us, 2)}
+            us = ms / args.iters * 1e3  # per call of the op (the weight gradient is up to three launches: list, GEMM, reduce)
+            k = {"us_per_call": round(us, 2), "launches_per_call": n / args.iters}
             fl = {"router_mfma": flops_fwd, "wgrad_mfma": flops_wgrad}.get(name)
             if fl:
                 k["TFLOPs"] = round(fl / (us * 1e-6) / 1e12, 2)
