@@ -129,6 +129,13 @@ __device__ __forceinline__ void axpy_frag(RowFrag<DCH>& acc, float a, const RowF
   }
 }
 template <int DCH>
+__device__ __forceinline__ void scale_frag(RowFrag<DCH>& f, float c) {
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    f.v[j].x *= c; f.v[j].y *= c; f.v[j].z *= c; f.v[j].w *= c;
+  }
+}
+template <int DCH>
 __device__ __forceinline__ void zero_frag(RowFrag<DCH>& f) {
 #pragma unroll
   for (int j = 0; j < DCH; ++j) f.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -240,6 +247,7 @@ __attribute__((visibility("hidden"))) int ic_heads_static_setup(float** out);
 // library-internal (router_mfma.hip): the shared-matrix (by_direction) forward / weight-gradient GEMMs on MFMA
 __attribute__((visibility("hidden"))) int ic_router_shared_fwd_launch(const ic_router_args* a, hipStream_t st);
 __attribute__((visibility("hidden"))) int ic_wgrad_shared_launch(const ic_wgrad_edge_args* a, hipStream_t st);
+__attribute__((visibility("hidden"))) int ic_router_shared_dgrad_launch(const ic_router_bwd_args* b, int nslab, hipStream_t st);
 
 // library-internal: gate + router edge launch of ic_front_fwd, with or without the combine launch
 __attribute__((visibility("hidden"))) int ic_front_launch(const ic_gate_args* g, const ic_router_args* a,

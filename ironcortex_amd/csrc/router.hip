@@ -262,7 +262,7 @@ __device__ __forceinline__ bool prev_on(const ic_router_bwd_args& b, int s, int 
 // precision mode the key/query gradients and the direct d/dH_dst term.
 // d > 256: the edges are walked one at a time (the all-at-once variant below would spill).
 template <int DCH>
-__global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_args b) {
+__global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_args b, int fold_bias) {
   const ic_router_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lrow = blockIdx.x * 4 + wave;
@@ -287,7 +287,15 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_ar
     const bool act = prev_on(b, s, a.src[e]);
     any |= act;
     if (lane == 0) b.tape_eact[(size_t)vs * a.E + e] = act ? 1 : 0;
-    if (act && !prec) store_row(G, b.tape_gmsg + ((size_t)vs * a.E + e) * d, d, lane);
+    if (act && !prec) {
+      if (fold_bias) {  // (MFMA input gradient: nothing folds the edge bias into the tape entry later)
+        RowFrag<DCH> Gb = G;
+        scale_frag(Gb, a.ebias[e]);
+        store_row(Gb, b.tape_gmsg + ((size_t)vs * a.E + e) * d, d, lane);
+      } else {
+        store_row(G, b.tape_gmsg + ((size_t)vs * a.E + e) * d, d, lane);
+      }
+    }
   }
   if (!prec) return;
   if (lane == 0) b.tape_qact[row] = any ? 1 : 0;
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd_serial(ic_router_bwd_ar
 
 // d <= 256: every operand of a destination's active edges is requested up front.
 template <int DCH>
-__global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
+__global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b, int fold_bias) {
   const ic_router_args& a = b.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lrow = blockIdx.x * 4 + wave;
@@ -395,7 +403,15 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b) {
     if (i < deg) {
       const int e = e0 + i;
       if (lane == 0) b.tape_eact[(size_t)vs * a.E + e] = act[i] ? 1 : 0;
-      if (act[i] && !prec) store_row(G, b.tape_gmsg + ((size_t)vs * a.E + e) * d, d, lane);
+      if (act[i] && !prec) {
+        if (fold_bias) {
+          RowFrag<DCH> Gb = G;
+          scale_frag(Gb, a.ebias[e]);
+          store_row(Gb, b.tape_gmsg + ((size_t)vs * a.E + e) * d, d, lane);
+        } else {
+          store_row(G, b.tape_gmsg + ((size_t)vs * a.E + e) * d, d, lane);
+        }
+      }
     }
   }
   if (!prec) return;
@@ -939,21 +955,43 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
   // the idle workgroups: 56 vs 29 us at R=512; 10M bench, S=16: 17 vs 33 us).  IC_BWD_SPLIT=0/1 forces one.
   static const int many_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return (e && e[0]) ? (e[0] == '0' ? 0 : 1) : -1; }();
   const bool many = many_env >= 0 ? many_env == 1 : a->S >= 8;
+  // shared matrices without precision routing, streams laid out plainly: the input gradient is ONE MFMA GEMM
+  // (router_mfma.hip) in place of the per-edge transposed GEMVs and the gather
+  const bool dgrad_mfma = (a->flags & IC_RF_SHARED) && !(a->flags & IC_RF_PRECISION) && a->E > 0 && !b->in_slot && b->sk <= 1 &&
+                          b->gH_sstride == 0 && a->d % 4 == 0 && a->nW >= 1 && a->nW <= 8 && ic_ceil_div(a->d, 128) <= nslab;
   if (a->d <= 256) {
     constexpr int DCH = 1;
-    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b));
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b, (int)dgrad_mfma));
+    if (dgrad_mfma) {
+      int rc2 = ic_router_shared_dgrad_launch(b, nslab, st);
+      if (rc2) return rc2;
+      IC_LAUNCH_CHECK("ic_router_bwd");
+      return IC_OK;
+    }
     if (ny > 0 && many) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 8, 4>), dim3(nslab, ny, nz), blk, 0, st, *b));
     else if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else if (a->d <= 512) {
     constexpr int DCH = 2;
-    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b));
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b, (int)dgrad_mfma));
+    if (dgrad_mfma) {
+      int rc2 = ic_router_shared_dgrad_launch(b, nslab, st);
+      if (rc2) return rc2;
+      IC_LAUNCH_CHECK("ic_router_bwd");
+      return IC_OK;
+    }
     if (ny > 0 && many) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 2, 4>), dim3(nslab, ny, nz), blk, 0, st, *b));
     else if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
   } else {
     constexpr int DCH = 4;
-    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b));
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b, (int)dgrad_mfma));
+    if (dgrad_mfma) {
+      int rc2 = ic_router_shared_dgrad_launch(b, nslab, st);
+      if (rc2) return rc2;
+      IC_LAUNCH_CHECK("ic_router_bwd");
+      return IC_OK;
+    }
     if (ny > 0 && many) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 2, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
     else if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 2>), dim3(nslab, ny, nz), blk, 0, st, *b));
     IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));

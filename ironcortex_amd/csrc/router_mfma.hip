@@ -333,6 +333,131 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(ic_wgrad_edge_args a, int 
   if (blockIdx.x == 0 && threadIdx.x == 0) a.touched[k] = 1;
 }
 
+// ---- input gradient of the shared-matrix forward (no precision routing):
+//   gH^T[d, N] = sum_k  W_k^T [d,d]  x  G_k [d,N]        N = S*R (stream, SENDER) columns,
+//   G_k[:, n] = gM[s, dst_e] for the out-edge e of n's sender with widx[e] == k (a hex region has at most one
+//   neighbour per direction), a zero column when the sender was inactive.  Per k the tile of W_k^T g is finished
+//   before the edge bias is applied, so d/d ebias_e = (W_k^T g) . h_sender comes out of the same accumulators
+//   (this workgroup's 128 rows: partial blockIdx.x of g_ebias_part).  Output-stationary like the forward: every
+//   (stream, sender) row of gH is written once, zeros for inactive senders; no slabs, no gather launch.
+__global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_args b) {
+  const ic_router_args& a = b.f;
+  __shared__ float As[kTM][kTK + 1];
+  __shared__ float Bs[kTK][kTN + 1];
+  __shared__ int tdst[kMaxShared][kTN], tedge[kMaxShared][kTN];
+  __shared__ float tscale[kMaxShared][kTN];
+  __shared__ int any_k[kMaxShared];
+  __shared__ float pb[4][kTN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = a.d, N = a.S * a.R;
+  const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * kTN;
+  if (tid < kMaxShared) any_k[tid] = 0;
+  __syncthreads();
+  {  // per column and matrix: the out-edge of the column's sender, its destination and bias, or -1
+    const int c = tid & 31, k = tid >> 5, n = col0 + c;
+    int dst = -1, edge = -1;
+    float sc = 0.f;
+    if (k < a.nW && n < N) {
+      const int s = n / a.R, r = n % a.R;
+      if (prev_on(a, s, r)) {  // (no in_slot / sk on this path: ic_router_bwd checks)
+        for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
+          const int e = b.src_edges[i];
+          if (a.widx[e] == k) {
+            edge = e;
+            sc = a.ebias[e];
+            int lo = 0, hi = a.R;  // destination of e: the r' with dst_off[r'] <= e < dst_off[r'+1]
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if (a.dst_off[mid] <= e) lo = mid; else hi = mid;
+            }
+            dst = lo;
+            break;
+          }
+        }
+      }
+    }
+    tdst[k][c] = dst;
+    tedge[k][c] = edge;
+    tscale[k][c] = sc;
+    if (dst >= 0) any_k[k] = 1;
+  }
+  __syncthreads();
+  const int j = lane & 31, n = col0 + j;
+  const int s_col = n < N ? n / a.R : 0, r_col = n < N ? n % a.R : 0;
+  // this lane's 16 rows of its column's sender state (for d/d ebias)
+  float hv[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) hv[v] = 0.f;
+  if (n < N) {
+    const float* hrow = h_row(a, s_col, r_col);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = row0 + wave * 32 + 8 * q + 4 * (lane >> 5);
+      if (i < d) {
+        const float4 t = *reinterpret_cast<const float4*>(hrow + i);
+        hv[4 * q] = t.x; hv[4 * q + 1] = t.y; hv[4 * q + 2] = t.z; hv[4 * q + 3] = t.w;
+      }
+    }
+  }
+  v16f tot;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) tot[v] = 0.f;
+  const int SE = a.S * a.E;
+  for (int k = 0; k < a.nW; ++k) {
+    if (!any_k[k]) continue;  // workgroup-uniform
+    const float* W = a.W + (size_t)k * d * d;
+    v16f acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    for (int kk0 = 0; kk0 < d; kk0 += kTK) {
+      {  // A[i][kk] = W_k[kk0 + kk][row0 + i]; thread -> (kk = tid / 8, 16 i's), rows of W read coalesced
+        const int kk = tid >> 3, i0 = (tid & 7) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = row0 + i0 + 4 * q;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kk0 + kk < d && i < d) v = *reinterpret_cast<const float4*>(W + (size_t)(kk0 + kk) * d + i);
+          As[i0 + 4 * q + 0][kk] = v.x; As[i0 + 4 * q + 1][kk] = v.y; As[i0 + 4 * q + 2][kk] = v.z; As[i0 + 4 * q + 3][kk] = v.w;
+        }
+      }
+      {  // B[kk][c] = gM[s, dst][kk0 + kk]; thread -> (column tid / 8, 4 k's)
+        const int c = tid >> 3, ks = (tid & 7) * 4, dst = tdst[k][c], nn = col0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dst >= 0 && kk0 + ks < d)
+          v = *reinterpret_cast<const float4*>(b.gM + ((size_t)(nn / a.R) * a.R + dst) * d + kk0 + ks);
+        Bs[ks + 0][c] = v.x; Bs[ks + 1][c] = v.y; Bs[ks + 2][c] = v.z; Bs[ks + 3][c] = v.w;
+      }
+      __syncthreads();
+      mfma_chunk(As, Bs, wave, lane, acc);
+      __syncthreads();
+    }
+    // d/d ebias of this column's edge: (W_k^T g) . h over this workgroup's rows, in a fixed order
+    float part = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) part = fmaf(acc[v], hv[v], part);
+    part += __shfl_xor(part, 32, 64);
+    if (lane < 32) pb[wave][j] = part;
+    const float sc = tscale[k][j];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) tot[v] = fmaf(sc, acc[v], tot[v]);
+    __syncthreads();
+    if (tid < kTN) {
+      const int e = tedge[k][tid], nn = col0 + tid;
+      if (e >= 0 && nn < N)
+        b.g_ebias_part[(size_t)blockIdx.x * SE + (size_t)(nn / a.R) * a.E + e] = (pb[0][tid] + pb[1][tid]) + (pb[2][tid] + pb[3][tid]);
+    }
+    __syncthreads();
+  }
+  if (n < N) {
+    float* out = b.gH + (size_t)n * d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = row0 + wave * 32 + 8 * q + 4 * (lane >> 5);
+      if (i < d) *reinterpret_cast<float4*>(out + i) = make_float4(tot[4 * q], tot[4 * q + 1], tot[4 * q + 2], tot[4 * q + 3]);
+    }
+  }
+}
+
 }  // namespace
 
 // library-internal launchers (router.hip: ic_router_fwd / ic_router_wgrad)
@@ -360,5 +485,14 @@ int ic_wgrad_shared_launch(const ic_wgrad_edge_args* a, hipStream_t st) {
     return IC_OK;
   }
   IC_TIMED(IC_KID_wgrad_mfma, st, hipLaunchKernelGGL(k_wgrad_shared_mfma, grid, dim3(256), 0, st, *a));
+  return IC_OK;
+}
+
+int ic_router_shared_dgrad_launch(const ic_router_bwd_args* b, int nslab, hipStream_t st) {
+  const ic_router_args* a = &b->f;
+  (void)nslab;
+  const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->S * a->R, kTN));
+  IC_BYTES(IC_KID_router_mfma, 4.0 * ((double)a->nW * a->d * a->d + 3.0 * a->S * a->R * a->d));
+  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_dgrad_mfma, grid, dim3(256), 0, st, *b));
   return IC_OK;
 }
