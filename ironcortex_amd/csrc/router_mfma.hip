@@ -67,28 +67,31 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
   for (int k = 0; k < a.nW; ++k) {
     if (!any_k[k]) continue;  // workgroup-uniform
     const float* W = a.W + (size_t)k * d * d;
-    for (int kk0 = 0; kk0 < d; kk0 += kTK) {
-      {  // A: rows row0.. of W_k, columns kk0..kk0+31; thread -> (row tid / 2, 16 columns)
-        const int r = tid >> 1, h = (tid & 1) * 16, grow = row0 + r;
+    // A: rows row0.. of W_k, columns kk0..kk0+31; thread -> (row tid / 2, 16 columns)
+    // B: the gathered, bias-scaled sender rows; thread -> (column tid / 8, 4 k's)
+    // The next chunk's operands are requested into registers before the current chunk's MFMAs run.
+    const int ar = tid >> 1, ah = (tid & 1) * 16, agrow = row0 + ar;
+    const int bc = tid >> 3, bks = (tid & 7) * 4, bsrow = tsrc[k][bc];
+    const float bsc = tscale[k][bc];
+    const float* brow = bsrow >= 0 ? h_row(a, (col0 + bc) / a.R, bsrow) : nullptr;
+    float4 av[4], bv;
+    auto fetch = [&](int kk0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int kk = kk0 + h + 4 * q;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (grow < d && kk < d) v = *reinterpret_cast<const float4*>(W + (size_t)grow * d + kk);
-          As[r][h + 4 * q + 0] = v.x; As[r][h + 4 * q + 1] = v.y; As[r][h + 4 * q + 2] = v.z; As[r][h + 4 * q + 3] = v.w;
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int kk = kk0 + ah + 4 * q;
+        av[q] = (agrow < d && kk < d) ? *reinterpret_cast<const float4*>(W + (size_t)agrow * d + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      {  // B: the gathered, bias-scaled sender rows; thread -> (column tid / 8, 4 k's)
-        const int c = tid >> 3, ks = (tid & 7) * 4, srow = tsrc[k][c], n = col0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (srow >= 0 && kk0 + ks < d) {
-          v = *reinterpret_cast<const float4*>(h_row(a, n / a.R, srow) + kk0 + ks);
-          const float sc = tscale[k][c];
-          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-        }
-        Bs[ks + 0][c] = v.x; Bs[ks + 1][c] = v.y; Bs[ks + 2][c] = v.z; Bs[ks + 3][c] = v.w;
+      bv = (brow && kk0 + bks < d) ? *reinterpret_cast<const float4*>(brow + kk0 + bks) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+    for (int kk0 = 0; kk0 < d; kk0 += kTK) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        As[ar][ah + 4 * q + 0] = av[q].x; As[ar][ah + 4 * q + 1] = av[q].y; As[ar][ah + 4 * q + 2] = av[q].z; As[ar][ah + 4 * q + 3] = av[q].w;
       }
+      Bs[bks + 0][bc] = bv.x * bsc; Bs[bks + 1][bc] = bv.y * bsc; Bs[bks + 2][bc] = bv.z * bsc; Bs[bks + 3][bc] = bv.w * bsc;
       __syncthreads();
+      if (kk0 + kTK < d) fetch(kk0 + kTK);
       mfma_chunk(As, Bs, wave, lane, acc);
       __syncthreads();
     }
@@ -274,28 +277,32 @@ __global__ __launch_bounds__(256) void k_wgrad_shared_mfma_list(ic_wgrad_edge_ar
   v16f acc;
 #pragma unroll
   for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-  for (int p0 = pb; p0 < P; p0 += kTK) {
-    {  // A[i][p] = g[pair p][row0 + i]; thread -> (pair tid % 32, 16 rows)
-      const int pp = tid & 31, i0 = (tid >> 5) * 16;
-      const float* g = p0 + pp < P ? a.tape_g + (size_t)list[p0 + pp] * d : nullptr;
+  // A[i][p] = g[pair p][row0 + i]; thread -> (pair tid % 32, 16 rows)
+  // B[p][j] = H[pair p's sender][col0 + j]; thread -> (pair tid / 8, 4 columns); next chunk prefetched into registers
+  const int app = tid & 31, ai0 = (tid >> 5) * 16, bpp = tid >> 3, bjs = (tid & 7) * 4;
+  float4 av[4], bv;
+  auto fetch = [&](int p0) {
+    const float* g = p0 + app < P ? a.tape_g + (size_t)list[p0 + app] * d : nullptr;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = row0 + i0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g && i < d) v = *reinterpret_cast<const float4*>(g + i);
-        As[i0 + 4 * q + 0][pp] = v.x; As[i0 + 4 * q + 1][pp] = v.y; As[i0 + 4 * q + 2][pp] = v.z; As[i0 + 4 * q + 3][pp] = v.w;
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int i = row0 + ai0 + 4 * q;
+      av[q] = (g && i < d) ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    {  // B[p][j] = H[pair p's sender][col0 + j]; thread -> (pair tid / 8, 4 columns)
-      const int pp = tid >> 3, js = (tid & 7) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p0 + pp < P && col0 + js < d) {
-        const int id = list[p0 + pp], ts = id / a.E, e = id - ts * a.E;
-        v = *reinterpret_cast<const float4*>(a.tape_H + ((size_t)ts * a.R + a.src[e]) * d + col0 + js);
-      }
-      Bs[pp][js + 0] = v.x; Bs[pp][js + 1] = v.y; Bs[pp][js + 2] = v.z; Bs[pp][js + 3] = v.w;
+    bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p0 + bpp < P && col0 + bjs < d) {
+      const int id = list[p0 + bpp], ts = id / a.E, e = id - ts * a.E;
+      bv = *reinterpret_cast<const float4*>(a.tape_H + ((size_t)ts * a.R + a.src[e]) * d + col0 + bjs);
     }
+  };
+  if (pb < P) fetch(pb);
+  for (int p0 = pb; p0 < P; p0 += kTK) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      As[ai0 + 4 * q + 0][app] = av[q].x; As[ai0 + 4 * q + 1][app] = av[q].y; As[ai0 + 4 * q + 2][app] = av[q].z; As[ai0 + 4 * q + 3][app] = av[q].w;
+    }
+    Bs[bpp][bjs + 0] = bv.x; Bs[bpp][bjs + 1] = bv.y; Bs[bpp][bjs + 2] = bv.z; Bs[bpp][bjs + 3] = bv.w;
     __syncthreads();
+    if (p0 + kTK < P) fetch(p0 + kTK);
     mfma_chunk(As, Bs, wave, lane, acc);
     __syncthreads();
   }
@@ -409,25 +416,29 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
     v16f acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-    for (int kk0 = 0; kk0 < d; kk0 += kTK) {
-      {  // A[i][kk] = W_k[kk0 + kk][row0 + i]; thread -> (kk = tid / 8, 16 i's), rows of W read coalesced
-        const int kk = tid >> 3, i0 = (tid & 7) * 16;
+    // A[i][kk] = W_k[kk0 + kk][row0 + i]; thread -> (kk = tid / 8, 16 i's), rows of W read coalesced
+    // B[kk][c] = gM[s, dst][kk0 + kk]; thread -> (column tid / 8, 4 k's); next chunk prefetched into registers
+    const int akk = tid >> 3, ai0 = (tid & 7) * 16;
+    const int bc = tid >> 3, bks = (tid & 7) * 4, bdst = tdst[k][bc];
+    const float* brow = bdst >= 0 ? b.gM + ((size_t)((col0 + bc) / a.R) * a.R + bdst) * d : nullptr;
+    float4 av[4], bv;
+    auto fetch = [&](int kk0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = row0 + i0 + 4 * q;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (kk0 + kk < d && i < d) v = *reinterpret_cast<const float4*>(W + (size_t)(kk0 + kk) * d + i);
-          As[i0 + 4 * q + 0][kk] = v.x; As[i0 + 4 * q + 1][kk] = v.y; As[i0 + 4 * q + 2][kk] = v.z; As[i0 + 4 * q + 3][kk] = v.w;
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int i = row0 + ai0 + 4 * q;
+        av[q] = (kk0 + akk < d && i < d) ? *reinterpret_cast<const float4*>(W + (size_t)(kk0 + akk) * d + i) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      {  // B[kk][c] = gM[s, dst][kk0 + kk]; thread -> (column tid / 8, 4 k's)
-        const int c = tid >> 3, ks = (tid & 7) * 4, dst = tdst[k][c], nn = col0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dst >= 0 && kk0 + ks < d)
-          v = *reinterpret_cast<const float4*>(b.gM + ((size_t)(nn / a.R) * a.R + dst) * d + kk0 + ks);
-        Bs[ks + 0][c] = v.x; Bs[ks + 1][c] = v.y; Bs[ks + 2][c] = v.z; Bs[ks + 3][c] = v.w;
+      bv = (brow && kk0 + bks < d) ? *reinterpret_cast<const float4*>(brow + kk0 + bks) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+    for (int kk0 = 0; kk0 < d; kk0 += kTK) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        As[ai0 + 4 * q + 0][akk] = av[q].x; As[ai0 + 4 * q + 1][akk] = av[q].y; As[ai0 + 4 * q + 2][akk] = av[q].z; As[ai0 + 4 * q + 3][akk] = av[q].w;
       }
+      Bs[bks + 0][bc] = bv.x; Bs[bks + 1][bc] = bv.y; Bs[bks + 2][bc] = bv.z; Bs[bks + 3][bc] = bv.w;
       __syncthreads();
+      if (kk0 + kTK < d) fetch(kk0 + kTK);
       mfma_chunk(As, Bs, wave, lane, acc);
       __syncthreads();
     }
