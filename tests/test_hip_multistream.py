@@ -141,3 +141,56 @@ def test_train_step_multi_mode_runs_and_strict_is_untouched():
     # strict mode still reproduces the real reference's first step exactly as before
     for k in ("ff", "total", "grad_norm"):
         assert out["strict"][k] == pytest.approx(float(gold[f"step0.{k}"]), rel=2e-5, abs=1e-6), k
+
+
+@pytest.mark.parametrize("variant", ["by_direction", "groups"])
+def test_multistream_by_direction_and_launch_groups(variant, monkeypatch):
+    """Two corners of the lockstep path, each stream again against an oracle batch-1 run from the same warmed state:
+    the shared-matrix router (edge_transform_mode="by_direction": the MFMA forward reads each stream's parent block
+    through in_slot), and a batch larger than one launch group (every group restarts from the state the call began
+    with; the bank ends with the last loop's)."""
+    import ironcortex_amd as ic
+    from ironcortex_amd.config import CortexConfig
+    from tests.model_cases import MODEL_CASES
+    kw = dict(MODEL_CASES["default"])
+    if variant == "by_direction":
+        kw["edge_transform_mode"] = "by_direction"
+    cfg = CortexConfig(**kw)
+    torch.manual_seed(5)
+    ref = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
+    with torch.no_grad():  # tie-free gate buffers (the reference's order on exact ties is the CPU sort's)
+        ref.gate.gain_ema.copy_(gi.det(51, cfg.R, scale=0.1))
+        ref.gate.homeo.copy_(gi.det(52, cfg.R, scale=0.1).abs())
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    N, T, K = 5, 24, cfg.K_inner
+    tokens, focus = _samples(cfg, N, T)
+    warm_t, warm_f = tokens[:1].flip(1), focus[:1]
+    om = OM.build(cfg)
+    om.load_state_dict(sd)
+    want = []
+    with torch.no_grad():
+        om.reasoning_loop_batch(warm_t, K, warm_f)
+        for j in range(N):
+            o = copy.deepcopy(om)
+            o.detach_state()
+            H0, m0 = o.zeros_state()
+            want.append(o.reasoning_loop(tokens[j], K, focus[j], m0, H0) + (o,))
+    model = build(cfg, sd)
+    if variant == "groups":
+        monkeypatch.setattr(type(model.engine), "MAX_LOCKSTEP_STREAMS", 4)  # 2 loops x 2 branches per launch group
+    with torch.no_grad():
+        model.reasoning_loop_batch(warm_t.to(DEV), K, warm_f.to(DEV))
+        model.stream_mode = "multi"
+        n0 = model.engine.counters["lockstep"]
+        H, m, logits, traces, en, ent = model.reasoning_loop_batch(tokens.to(DEV), K, focus.to(DEV))
+    assert model.engine.counters["lockstep"] - n0 == (3 if variant == "groups" else 1)
+    tag = f"multistream/{variant}"
+    for j, (Hw, mw, lw, tw, o) in enumerate(want):
+        assert np.array_equal(m[j].cpu().numpy(), mw.numpy()), j
+        assert np.array_equal(H[j].cpu().numpy() != 0, Hw.numpy() != 0), j
+        PL.check(tag, f"H[{j}]", H[j], Hw, TOL_STATE)
+        PL.check(tag, f"logits[{j}]", logits[j], lw, TOL_STATE)
+        PL.check(tag, f"traces[{j}]", torch.stack(traces[j]), torch.stack(tw), TOL_STATE)
+    PL.check(tag, "num", model.bank.num[0], torch.stack([c.st["num"] for c in want[-1][4].regions]), TOL_STATE)
+    PL.check(tag, "slots", model.work.slots, want[-1][4].work.slots, TOL_STATE)
+    PL.flush(tag)
