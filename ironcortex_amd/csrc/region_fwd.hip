@@ -168,10 +168,13 @@ __global__ __launch_bounds__(256) void k_region_pro(ic_region_args a) {
 // the answer is a ballot: with hundreds of regions most workgroups of a launch are idle, and how
 // fast they leave (one memory round trip, not one per stream) decides how soon the working ones
 // get their slots.
+// The slice kernels may split the streams over gridDim.z (workgroup z serves streams z, z + nz, ...): with many
+// streams and few regions (the lockstep loops: S = 16, R = 10) a workgroup's serial walk over its active streams,
+// not the weight rows it re-reads from L2, bounds the launch.  nz = 1 (always for IC_F_CHAIN) is the plain walk.
 __device__ __forceinline__ bool region_has_work(const uint8_t* mask, int S, int R, int r) {
-  const int lane = threadIdx.x & 63;
-  for (int sc = 0; sc < S; sc += 64) {
-    const int s = sc + lane;
+  const int lane = threadIdx.x & 63, nz = gridDim.z;
+  for (int sc = blockIdx.z; sc < S; sc += 64 * nz) {
+    const int s = sc + lane * nz;
     if (__ballot(s < S && mask[(size_t)s * R + r] != 0)) return true;
   }
   return false;
@@ -307,16 +310,17 @@ __device__ __forceinline__ void region_rkv_body(const ic_region_args& a, float o
       }
     }
   };
-  for (int sc = 0; sc < a.S; sc += 64) {
-    const int sl = sc + lane;
+  const int nz = gridDim.z;
+  for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+    const int sl = sc + lane * nz;
     unsigned long long act = __ballot(sl < a.S && a.mask[sl * a.R + r] != 0);
     if (!act) continue;
     Ops cur, nxt;
-    int s_cur = sc + __ffsll((long long)act) - 1;
+    int s_cur = sc + (__ffsll((long long)act) - 1) * nz;
     act &= act - 1;
     request(s_cur, -1, cur);
     while (s_cur >= 0) {
-      const int s_nxt = act ? sc + __ffsll((long long)act) - 1 : -1;
+      const int s_nxt = act ? sc + (__ffsll((long long)act) - 1) * nz : -1;
       act &= act - 1;
       if (s_nxt >= 0) request(s_nxt, s_cur, nxt);
       const int row = s_cur * a.R + r;
@@ -432,16 +436,17 @@ __global__ __launch_bounds__(256) void k_region_out(ic_region_args a) {
       o.xres[p] = (lane < 2 && ch < d) ? a.x[(size_t)row * d + ch] : 0.f;
     }
   };
-  for (int sc = 0; sc < a.S; sc += 64) {
-    const int sl = sc + lane;
+  const int nz = gridDim.z;
+  for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+    const int sl = sc + lane * nz;
     unsigned long long act = __ballot(sl < a.S && a.mask[sl * a.R + r] != 0);
     if (!act) continue;
     Ops cur, nxt;
-    int s_cur = sc + __ffsll((long long)act) - 1;
+    int s_cur = sc + (__ffsll((long long)act) - 1) * nz;
     act &= act - 1;
     request(s_cur, cur);
     while (s_cur >= 0) {
-      const int s_nxt = act ? sc + __ffsll((long long)act) - 1 : -1;
+      const int s_nxt = act ? sc + (__ffsll((long long)act) - 1) * nz : -1;
       act &= act - 1;
       if (s_nxt >= 0) request(s_nxt, nxt);
       const int row = s_cur * a.R + r;
@@ -737,7 +742,11 @@ static int region_phase_launch(const ic_region_args* a, const ic_router_args* ra
   if (a->d > 256 && rpb > 16) rpb = 16;  // register budget at DCH >= 2
   if (a->d > 512 && rpb > 8) rpb = 8;    // DCH = 4: 16 rows of three matrices would spill
   if (a->d > 256 && rpb_out > 16) rpb_out = 16;
-  const dim3 gmat(ic_ceil_div(a->d, rpb), a->R), gout(ic_ceil_div(a->d, rpb_out), a->R);
+  // streams over gridDim.z when the slices x regions alone leave most of the chip idle (never for a state chain)
+  int nz = 1;
+  if (!(a->flags & IC_F_CHAIN) && !ra)
+    while (nz < a->S && nz < 16 && ic_ceil_div(a->d, rpb) * a->R * nz < 1024) nz *= 2;
+  const dim3 gmat(ic_ceil_div(a->d, rpb), a->R, nz), gout(ic_ceil_div(a->d, rpb_out), a->R, nz);
   const float oma = (float)(1.0 - a->pred_alpha);
   const bool chain = a->flags & IC_F_CHAIN;
   IC_REQUIRE(!chain || a->S <= 64, "ic_region_phase_fwd: IC_F_CHAIN needs S <= 64 (S=%d)", a->S);

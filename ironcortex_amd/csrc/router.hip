@@ -91,8 +91,10 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
   const size_t dd = (size_t)d * d;
   if (y < a.E) {
     const int e = y, src = a.src[e];
+    const int nz = gridDim.z;  // streams z, z + nz, ... (gridDim.z > 1: many streams, see ic_front_launch)
     bool any = false;  // lanes test 64 streams per round trip: idle workgroups leave quickly
-    for (int sc = 0; sc < a.S && !any; sc += 64) any = __ballot(sc + lane < a.S && prev_on(a, sc + lane, src)) != 0;
+    for (int sc = blockIdx.z; sc < a.S && !any; sc += 64 * nz)
+      any = __ballot(sc + lane * nz < a.S && prev_on(a, sc + lane * nz, src)) != 0;
     if (!any) return;
     const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
     const float* K = a.key_W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
     load_row(k0, K, d, lane);
     load_row(k1, K + d, d, lane);
     const float bias = a.ebias[e];
-    for (int s = 0; s < a.S; ++s) {
+    for (int s = blockIdx.z; s < a.S; s += nz) {
       if (!prev_on(a, s, src)) continue;
       load_row(h, h_row(a, s, src), d, lane);
       const float m0 = wave_sum(dot_frag(w0, h)), m1 = wave_sum(dot_frag(w1, h));
@@ -119,7 +121,7 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
     const float* Q = a.query_W + (size_t)r * dd + (size_t)row0 * d;
     RowFrag<DCH> q0, q1, h;
     bool loaded = false;
-    for (int s = 0; s < a.S; ++s) {
+    for (int s = blockIdx.z; s < a.S; s += gridDim.z) {
       bool any = false;
       for (int e = e0; e < e1; ++e) any |= prev_on(a, s, a.src[e]);
       if (!any) continue;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
 template <int DCH, bool PRECISION>
 __global__ __launch_bounds__(256) void k_front(ic_router_args a, ic_gate_args g) {
   if ((int)blockIdx.y < g.S) {
-    if (blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || blockIdx.z != 0) return;
     __shared__ float sc[1024];
     __shared__ int order[1024];
     __shared__ uint8_t supp[1024];
@@ -870,6 +872,14 @@ static int check_router(const ic_router_args* a, const char* who) {
   return IC_OK;
 }
 
+// precision routing: an edge's workgroup walks its streams one after the other (sender mask byte, sender row, four
+// reductions each); with many streams they are split over gridDim.z, at most ~4-8 streams per workgroup
+static int edge_nz(int S) {
+  int nz = 1;
+  while (nz * 8 <= S && nz < 8) nz *= 2;
+  return nz;
+}
+
 extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
   int rc = check_router(a, "ic_router_fwd");
   if (rc) return rc;
@@ -877,7 +887,7 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
   const int nsl = ic_ceil_div(a->d, kRowsPerBlock);
   if (a->flags & IC_RF_PRECISION) {
     IC_DISPATCH_DCH(a->d, {
-      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R), dim3(256), 0, st, *a));
+      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R, edge_nz(a->S)), dim3(256), 0, st, *a));
     });
     const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
     if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
@@ -915,7 +925,7 @@ int ic_front_launch(const ic_gate_args* g, const ic_router_args* a, ic_stream_t 
   const int nsl = ic_ceil_div(a->d, kRowsPerBlock);
   if (a->flags & IC_RF_PRECISION) {
     IC_DISPATCH_DCH(a->d, {
-      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_front<DCH, true>), dim3(nsl, g->S + a->E + a->R), dim3(256), 0, st, *a, *g));
+      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_front<DCH, true>), dim3(nsl, g->S + a->E + a->R, edge_nz(a->S)), dim3(256), 0, st, *a, *g));
     });
     const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
     if (!combine) {

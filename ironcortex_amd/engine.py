@@ -1119,9 +1119,7 @@ class LoopEngine:
         done = [False] * N                        # the loop has halted (reference should_halt) or finished
         halt_now = [False] * N
         best, n_steps = [-1] * N, [0] * N
-        traces: List[List[torch.Tensor]] = [[] for _ in range(N)]
-        keep_tr = (lambda t: t) if (grad and m._logits_detached) else (lambda t: t.clone())
-        Hf = f["H"]
+        trace_steps: List[List[int]] = [[] for _ in range(N)]  # the winner of every executed iteration (tensors at the end)
 
         def settle(k_prev: int) -> None:
             """Scores of iteration k_prev are in the pinned block: winner, next parents, u_mean, v_hat per loop."""
@@ -1136,7 +1134,7 @@ class LoopEngine:
                     top = [0]
                 w = t0_ + top[0]
                 best[j] = w
-                traces[j].append(keep_tr(Hf[base + w * N + j]))
+                trace_steps[j].append(w)
                 if halt_now[j] or k_prev + 1 >= K:
                     done[j] = True
                     continue
@@ -1163,21 +1161,18 @@ class LoopEngine:
                     settle(k - 1)
                     if all(done):
                         break
-                # per-stream inputs of this iteration's launches
+                # per-stream inputs of this iteration's launches (stream s = b * N + j), written a slice at a time
+                kt = [cfg.k_active] * N if det else [max(0, cfg.k_active + schedule_burst(u_mean[j], v_hat[j], R)) for j in range(N)]
+                t5 = [0.0] * N if det else [w5 * v for v in v_hat]
+                t6 = [w6 * u for u in u_mean]
+                for b in range(C):
+                    ci[b * N:(b + 1) * N] = [j if pars[j][b] < 0 else N + pars[j][b] * N + j for j in range(N)]
+                    ci[S + b * N:S + (b + 1) * N] = kt
+                    cf[2 * S + b * N:2 * S + (b + 1) * N] = t5
+                    cf[3 * S + b * N:3 * S + (b + 1) * N] = t6
                 for j in range(N):
-                    if det:
-                        bias, burst = 0.0, 0
-                    else:
-                        bias, burst = v_hat[j], schedule_burst(u_mean[j], v_hat[j], R)
-                    for b in range(C):
-                        s_ = b * N + j
-                        p_ = pars[j][b]
-                        ci[s_] = j if p_ < 0 else N + p_ * N + j
-                        ci[S + s_] = max(0, cfg.k_active + burst)
-                        cf[2 * S + s_] = w5 * bias
-                        cf[3 * S + s_] = w6 * u_mean[j]
-                        if not done[j]:
-                            parent[j].append(p_)
+                    if not done[j]:
+                        parent[j].extend(pars[j])
                 gate.value_bias = 0.0 if det else v_hat[N - 1]
                 ctl_dev.copy_(ctl_host, non_blocking=True)
                 a0 = base + k * C * N
@@ -1255,10 +1250,18 @@ class LoopEngine:
                 settle(k_last)
 
         # ---- results; the bank continues from the last loop's final state (views of its last slot)
-        bslot = torch.tensor([base + best[j] * N + j for j in range(N)], device=dev)
-        lslot = torch.tensor([base + (n_steps[j] - 1) * N + j for j in range(N)], device=dev)
+        # one index tensor for everything gathered out of the arena: winners, last steps, every iteration's winner
+        flat_tr = [base + w * N + j for j in range(N) for w in trace_steps[j]]
+        idx = torch.tensor([base + best[j] * N + j for j in range(N)] + [base + (n_steps[j] - 1) * N + j for j in range(N)]
+                           + flat_tr, device=dev)
+        bslot, lslot = idx[:N], idx[N:2 * N]
         masks = f["mask"][bslot]
         logits = f["logits"][lslot]
+        tr_rows = f["H"][idx[2 * N:]]  # (a copy: valid after the arena is recycled)
+        traces, o_ = [], 0
+        for j in range(N):
+            traces.append(list(tr_rows[o_:o_ + len(trace_steps[j])].unbind(0)))
+            o_ += len(trace_steps[j])
         jl = N - 1
         li = base + (n_steps[jl] - 1) * N + jl
         nar = torch.narrow
