@@ -201,6 +201,7 @@ class LoopEngine:
         self.flush_units()
         self._sess = None
         self._vhat0 = None
+        self._vhat0_pending = None
         self._hs_ok = set()  # parameters may have moved since: _heads_setup checks every pointer again
         if self._arena is not None:
             self._arena.reset()
@@ -218,6 +219,46 @@ class LoopEngine:
         if m.router._tape is not None:
             m.router._tape.reset()
         self.reset()
+        self._prefetch_vhat0()
+
+    def _prefetch_vhat0(self) -> None:
+        """Every loop of a train_step starts from the all-zero state, so the critic value that steers its first
+        iteration is the same for all of them and depends on the parameters alone: launch its chain NOW, while
+        the stream is empty, and read it when the first loop needs it (an event, not a stream sync: by then the
+        token mixer's kernels are queued behind it)."""
+        m = self.model
+        try:
+            dev = m.reg_coords.device
+            if (not self.enabled or dev.type != "cuda" or m.plan is None or m.cfg.train_deterministic_inner_loop
+                    or m.cfg.profile or m.cfg.ff_dropout):
+                return
+            z = getattr(self, "_zero_state", None)
+            if z is None or z[0].device != dev or z[0].shape != (m.R, m.d):
+                z = self._zero_state = (torch.zeros(m.R, m.d, device=dev), torch.zeros(m.R, dtype=_U8, device=dev))
+            hs = self._heads_setup(dev)
+            sa, steer = hs["sa"], hs["steer"]
+            L, st = lib(), stream_handle()
+            sa.n_cand = 1
+            sa.H_cand[0], sa.mask_cand[0] = z[0].data_ptr(), z[1].data_ptr()
+            sa.scores = None
+            for g in steer:
+                g.nbatch = 1
+            rc = L.ic_steer_select(ctypes.byref(sa), st) or L.ic_gemv_chain(steer, 6, st)
+            if rc:
+                check(rc, "ic_steer_select/ic_gemv_chain")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._vhat0_pending = (ev, hs["buf"]["ls"], hs["off"][1], dev)
+        except Exception:
+            self._vhat0_pending = None
+            raise
+
+    def _resolve_vhat0(self, dev) -> None:
+        p, self._vhat0_pending = getattr(self, "_vhat0_pending", None), None
+        if p is None or self._vhat0 is not None or p[3] != dev:
+            return
+        p[0].synchronize()
+        self._vhat0 = float(p[1][p[2]])
 
     def _rescue_state(self) -> None:
         self.resolve_pending()
@@ -299,6 +340,8 @@ class LoopEngine:
         arena = self._get_arena(dev, n_max)
         if not grad:
             self.reset()  # nothing is kept from a no-grad loop: outputs are cloned below
+        elif H_prev is getattr(m, "_zero_H", None):
+            self._resolve_vhat0(dev)
         chunk, i0 = arena.reserve(max(1, n_max), dev)
         CP, CS = chunk.ptr, chunk.stride
 
@@ -1143,6 +1186,8 @@ class LoopEngine:
                 v_hat[j] = 0.0 if det else vals[o_vhat + top[0] * N + j]
 
         if not det:
+            if grad:
+                self._resolve_vhat0(dev)
             v0 = self._vhat_zero_state(dev, Hb, Mb)
             v_hat = [v0] * N
         k_last, was_planned = -1, False
