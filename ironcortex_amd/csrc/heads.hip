@@ -503,6 +503,72 @@ __device__ __forceinline__ ic_heads_args heads_stream(ic_heads_args a, int s) {
   return a;
 }
 
+// token_rows for a batch of streams [s0, s1) (at most kHeadsSB): the two weight rows of a wave are read ONCE for the
+// batch and the streams' input rows are all requested before the first reduction -- with 32 lockstep streams
+// the per-stream grid re-read the 4.7 MB of head weights 32 times from L2 (30 us); same sums per stream.
+constexpr int kHeadsSB = 8;
+template <int DCH>
+__device__ __forceinline__ void token_rows_multi(const ic_heads_args& a0, int lane, int wave, const int grp, const int xb,
+                                                 const int s0, const int s1) {
+  const int d = a0.d;
+  const int rows = grp == 0 ? a0.Kf + a0.Kf * a0.V : a0.V;
+  const int row0 = xb * 8 + wave * 2;
+  const int r = grp - 1;
+  RowFrag<DCH> xv[kHeadsSB];
+  bool on[kHeadsSB];
+  bool any = false;
+#pragma unroll
+  for (int u = 0; u < kHeadsSB; ++u) {
+    on[u] = false;
+    zero_frag(xv[u]);
+    if (s0 + u < s1) {
+      const ic_heads_args a = heads_stream(a0, s0 + u);
+      on[u] = grp == 0 || (r != a.motor_idx && a.mask[r] != 0);
+      if (on[u] && row0 < rows) load_row(xv[u], a.H + (size_t)(grp == 0 ? a.motor_idx : r) * d, d, lane);
+      any |= on[u];
+    }
+  }
+  RowFrag<DCH> w[2];
+  float bias[2] = {0.f, 0.f};
+  zero_frag(w[0]);
+  zero_frag(w[1]);
+  if (any && row0 < rows) {
+    const float* W = grp == 0 ? a0.lm_W - (size_t)a0.Kf * d : a0.rh_W + (size_t)r * a0.V * d;  // facet row i sits at z[Kf + i]
+    const float* b = grp == 0 ? a0.lm_b - a0.Kf : a0.rh_b + (size_t)r * a0.V;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = row0 + i;
+      if (row < rows) {
+        const float* wr = W + (size_t)row * d;
+        const float* br = b + row;
+        if (grp == 0 && row < a0.Kf) {  // the MFS gate rows come first in z
+          wr = a0.lm_gate_W + (size_t)row * d;
+          br = a0.lm_gate_b + row;
+        }
+        load_row(w[i], wr, d, lane);
+        bias[i] = *br;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kHeadsSB; ++u) {
+    if (s0 + u >= s1) break;
+    const ic_heads_args a = heads_stream(a0, s0 + u);
+    if (!on[u]) {  // not part of the mean (model.py:314-317): zeros, so the combine can add all R rows
+      const int v = xb * 8 + (int)threadIdx.x;  // this block's 8 rows (threads 0..7)
+      if (threadIdx.x < 8 && v < a.V) a.per_region[(size_t)r * a.V + v] = 0.f;
+      continue;
+    }
+    if (row0 >= rows) continue;
+    float* y = grp == 0 ? a.z : a.per_region + (size_t)r * a.V;
+    const float t0 = wave_sum(dot_frag(w[0], xv[u])), t1 = wave_sum(dot_frag(w[1], xv[u]));
+    if (lane == 0) {
+      y[row0] = t0 + bias[0];
+      if (row0 + 1 < rows) y[row0 + 1] = t1 + bias[1];
+    }
+  }
+}
+
 // mean of the active rows of H (same arithmetic as k_steer_select): one workgroup per stream
 __device__ __forceinline__ void ws_mean_rows(const ic_heads_args& a) {
   float n_on = 0.f;
@@ -589,26 +655,33 @@ __device__ __forceinline__ void gemv_on_ws_mean(const ic_heads_args& a, const ic
 // [workspace write: ceil(n_slots/4)] [row sums of squares: ceil(R/4)] [ws_mean: 1 if asked for]
 // [a GEMV on that mean: ceil(rows/8) if asked for]
 template <int DCH>
-__global__ __launch_bounds__(256) void k_heads(ic_heads_args a0, ic_gemv_desc g0, int n_g) {
-  const ic_heads_args a = heads_stream(a0, blockIdx.y);
+__global__ __launch_bounds__(256) void k_heads(ic_heads_args a0, ic_gemv_desc g0, int n_g, int sb) {
+  // blockIdx.y = a batch of up to kHeadsSB streams: the head rows serve the whole batch from one read of their
+  // weights, the small per-stream pieces run stream after stream
+  const int S = a0.S > 1 ? a0.S : 1;
+  const int s0 = blockIdx.y * sb, s1 = min(S, s0 + sb);  // sb = 1 (few streams: one workgroup row per stream) or kHeadsSB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int b = blockIdx.x;
-  const int n_tok = (a.Kf + a.Kf * a.V + 7) / 8, n_rh = (a.V + 7) / 8;
-  if (b < n_tok) return token_rows<DCH>(a, lane, wave, 0, b);
+  const int n_tok = (a0.Kf + a0.Kf * a0.V + 7) / 8, n_rh = (a0.V + 7) / 8;
+  if (b < n_tok) return token_rows_multi<DCH>(a0, lane, wave, 0, b, s0, s1);
   b -= n_tok;
-  if (b < a.R * n_rh) return token_rows<DCH>(a, lane, wave, 1 + b / n_rh, b % n_rh);
-  b -= a.R * n_rh;
-  const int n_ws = (a.n_slots + 3) / 4;
-  if (b < n_ws) return ws_write_rows<DCH>(a, lane, wave, b);
-  b -= n_ws;
-  const int n_sq = (a.R + 3) / 4;
-  if (b < n_sq) return sq_rows<DCH>(a, lane, wave, b);
-  b -= n_sq;
-  if (a.ws_mean) {
-    if (b == 0) return ws_mean_rows(a);
-    b -= 1;
+  if (b < a0.R * n_rh) return token_rows_multi<DCH>(a0, lane, wave, 1 + b / n_rh, b % n_rh, s0, s1);
+  b -= a0.R * n_rh;
+  for (int s = s0; s < s1; ++s) {
+    const ic_heads_args a = heads_stream(a0, s);
+    int c = b;
+    const int n_ws = (a.n_slots + 3) / 4;
+    if (c < n_ws) { ws_write_rows<DCH>(a, lane, wave, c); continue; }
+    c -= n_ws;
+    const int n_sq = (a.R + 3) / 4;
+    if (c < n_sq) { sq_rows<DCH>(a, lane, wave, c); continue; }
+    c -= n_sq;
+    if (a.ws_mean) {
+      if (c == 0) { ws_mean_rows(a); continue; }
+      c -= 1;
+    }
+    if (c < n_g) gemv_on_ws_mean<4 * DCH>(a, gemv_batch(g0, s), c);
   }
-  if (b < n_g) gemv_on_ws_mean<4 * DCH>(a, gemv_batch(g0, blockIdx.y), b);
 }
 
 __global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a0) {
@@ -817,6 +890,7 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_ge
   const int nblk = ic_ceil_div(a->Kf + a->Kf * a->V, 8) + a->R * ic_ceil_div(a->V, 8) + ic_ceil_div(a->n_slots, 4) +
                    ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0) + n_g;
   ic_gemv_desc g_none = {};
+  const int sb = S > 4 ? kHeadsSB : 1;  // (two branches of one loop: 9 us per stream row against 14 us batched)
   if (timed) {
     // shape-determined part: MFS gate + facets, the two state blocks (goodness terms), workspace rows, the riding
     // GEMV; the region-head rows of the ACTIVE regions (V x d each) are added by the caller from its unit counts
@@ -825,7 +899,7 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_ge
     IC_BYTES(IC_KID_logits_combine, 4.0 * (double)S * (a->Kf + (double)a->Kf * a->V + (double)a->R * a->V + 4.0 * a->V) + (g ? gemv_bytes(*g) : 0.0));
   }
   IC_DISPATCH_DCH(a->d, {
-    IC_MAYBE_TIMED(timed, IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, S), dim3(256), 0, st, *a, gm ? *gm : g_none, n_g));
+    IC_MAYBE_TIMED(timed, IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, ic_ceil_div(S, sb)), dim3(256), 0, st, *a, gm ? *gm : g_none, n_g, sb));
   });
   if (g) {
     const int cols = g->n0 + g->n1 + g->n2, nb = g->nbatch > 1 ? g->nbatch : 1;

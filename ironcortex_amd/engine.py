@@ -1339,7 +1339,8 @@ class LoopEngine:
             s.ebias_grad = bool(ebias.requires_grad)
             s.zero_in = True
             samples.append(s)
-        bt = {"samples": samples, "chunk": chunk, "base": base, "n_max": KC, "n_loops": N, "lockstep": True}
+        bt = {"samples": samples, "chunk": chunk, "base": base, "n_max": KC, "n_loops": N, "lockstep": True,
+              "H_out": f["H"][bslot]}  # (one gather instead of a row index per loop)
         H_out = LoopBatchFn.apply(sensors, bank.anchor(dev), self, bt)
         return H_out, masks, logits, traces
 
@@ -1866,6 +1867,8 @@ class LoopBatchFn(torch.autograd.Function):
     def forward(ctx, sensors, anchor, engine, bt):
         ctx.engine, ctx.bt = engine, bt
         ctx.sshape = sensors.shape
+        if bt.get("H_out") is not None:
+            return bt.pop("H_out")
         return torch.stack([s.chunk.fields["H"][s.i0 + s.best * s.ts] for s in bt["samples"]])
 
     @staticmethod
