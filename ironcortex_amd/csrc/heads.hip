@@ -667,21 +667,22 @@ __global__ __launch_bounds__(256) void k_heads(ic_heads_args a0, ic_gemv_desc g0
   b -= n_tok;
   if (b < a0.R * n_rh) return token_rows_multi<DCH>(a0, lane, wave, 1 + b / n_rh, b % n_rh, s0, s1);
   b -= a0.R * n_rh;
-  for (int s = s0; s < s1; ++s) {
-    const ic_heads_args a = heads_stream(a0, s);
-    int c = b;
-    const int n_ws = (a.n_slots + 3) / 4;
-    if (c < n_ws) { ws_write_rows<DCH>(a, lane, wave, c); continue; }
-    c -= n_ws;
-    const int n_sq = (a.R + 3) / 4;
-    if (c < n_sq) { sq_rows<DCH>(a, lane, wave, c); continue; }
-    c -= n_sq;
-    if (a.ws_mean) {
-      if (c == 0) { ws_mean_rows(a); continue; }
-      c -= 1;
-    }
-    if (c < n_g) gemv_on_ws_mean<4 * DCH>(a, gemv_batch(g0, s), c);
+  // the small per-stream pieces keep a workgroup of their own per stream: n_small blocks for each stream of the batch
+  const int n_ws = (a0.n_slots + 3) / 4, n_sq = (a0.R + 3) / 4;
+  const int n_small = n_ws + n_sq + (a0.ws_mean ? 1 : 0) + n_g;
+  const int s = s0 + b / n_small;
+  if (s >= s1) return;
+  const ic_heads_args a = heads_stream(a0, s);
+  int c = b % n_small;
+  if (c < n_ws) return ws_write_rows<DCH>(a, lane, wave, c);
+  c -= n_ws;
+  if (c < n_sq) return sq_rows<DCH>(a, lane, wave, c);
+  c -= n_sq;
+  if (a.ws_mean) {
+    if (c == 0) return ws_mean_rows(a);
+    c -= 1;
   }
+  if (c < n_g) gemv_on_ws_mean<4 * DCH>(a, gemv_batch(g0, s), c);
 }
 
 __global__ __launch_bounds__(256) void k_logits_combine(ic_heads_args a0) {
@@ -887,10 +888,10 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_ge
   const int S = a->S > 1 ? a->S : 1;
   IC_REQUIRE(S <= 64, "ic_heads_fwd: S=%d (need <= 64)", S);
   const int n_g = gm ? ic_ceil_div(gm->rows, 8) : 0;
-  const int nblk = ic_ceil_div(a->Kf + a->Kf * a->V, 8) + a->R * ic_ceil_div(a->V, 8) + ic_ceil_div(a->n_slots, 4) +
-                   ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0) + n_g;
-  ic_gemv_desc g_none = {};
   const int sb = S > 4 ? kHeadsSB : 1;  // (two branches of one loop: 9 us per stream row against 14 us batched)
+  const int nblk = ic_ceil_div(a->Kf + a->Kf * a->V, 8) + a->R * ic_ceil_div(a->V, 8) +
+                   sb * (ic_ceil_div(a->n_slots, 4) + ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0) + n_g);
+  ic_gemv_desc g_none = {};
   if (timed) {
     // shape-determined part: MFS gate + facets, the two state blocks (goodness terms), workspace rows, the riding
     // GEMV; the region-head rows of the ACTIVE regions (V x d each) are added by the caller from its unit counts
