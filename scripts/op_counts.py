@@ -44,6 +44,10 @@ import collections
 cnt = collections.defaultdict(lambda: collections.Counter())
 for e in ev:
     if e.name.startswith("aten::") and e.cpu_parent is not None and not e.cpu_parent.name.startswith("aten::"):
-        cnt[phase_of(e.time_range.start)][e.name] += 1
+        par = e.cpu_parent.name
+        key = e.name if par.startswith("PHASE_") else e.name + " <- " + par[:40]
+        cnt[phase_of(e.time_range.start)][key] += 1
 for ph, c in cnt.items():
-    print(ph, sum(c.values()), c.most_common(14))
+    print(ph, sum(c.values()))
+    for k_, v_ in c.most_common(40):
+        print("   ", v_, k_)
