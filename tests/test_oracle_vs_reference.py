@@ -201,6 +201,21 @@ def test_gate_tie_policy_documented():
         assert O.nms_topk(torch.zeros(R), 6, nb, stable=True) == gold[f"tie_zero.{R}"].tolist()
         z = torch.zeros(R); z[0] = 0.5; z[R - 1] = 0.5
         assert O.nms_topk(z, 6, nb, stable=True) == gold[f"tie_two.{R}"].tolist()
+    # R > 16: the reference's walk over exactly tied scores follows torch.argsort's unstable order (declared
+    # deviation).  What must still hold between its recorded picks and the build's: the same number of
+    # picks, the same scores picked (the strictly larger scores always come first), and both sets free of neighbours.
+    for R in (36, 64, 512):
+        nb = O.hex_neighbors(R)
+        for name, z in (("tie_zero", torch.zeros(R)), ("tie_two", None)):
+            if z is None:
+                z = torch.zeros(R); z[0] = 0.5; z[R - 1] = 0.5
+            ref, got = gold[f"{name}.{R}"].tolist(), O.nms_topk(z, 6, nb, stable=True)
+            assert len(got) == len(ref), (R, name, got, ref)
+            assert sorted(z[got].tolist()) == sorted(z[ref].tolist()), (R, name)
+            for picks in (ref, got):
+                assert all(q not in nb[p_] for p_ in picks for q in picks), (R, name, picks)
+            if name == "tie_two":  # the two strictly larger scores lead both walks, in index order on their tie
+                assert set(got[:2]) == set(ref[:2]) == {0, R - 1}
     # k_total == 0 still selects one region (utils.py:118-120)
     assert len(O.nms_topk(torch.tensor([0.1, 0.9, 0.3]), 0, [[1], [0, 2], [1]])) == 1
 
