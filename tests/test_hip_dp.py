@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, q):
+def _rank_main(rank, world, port, q, mode="strict"):
     try:
         import faulthandler
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,6 +44,7 @@ def _rank_main(rank, world, port, q):
         def build():
             m = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
             m.load_state_dict(sd)
+            m.stream_mode = mode
             return m.to(dev)
 
         import time
@@ -115,12 +116,13 @@ def _rank_main(rank, world, port, q):
         q.put((rank, "fail", traceback.format_exc()[-3000:]))
 
 
-def test_dp2_train_step_on_one_gpu_over_gloo():
+@pytest.mark.parametrize("mode", ["strict", "multi"])
+def test_dp2_train_step_on_one_gpu_over_gloo(mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = []
