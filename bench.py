@@ -96,6 +96,9 @@ def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
         "kwta_rows": st.get("rows", 0) * 3 * vec, "goodness_fwd": st.get("rows", 0) * vec, "goodness_bwd": st.get("rows", 0) * 2 * vec,
         "hebbian": st.get("e_upd", 0) * dd * 2,
     }
+    if st.get("fsplit"):  # >= 32 streams per launch: k_region_rkvG (weights, x row in, 3 raw rows out) + k_region_state
+        table["region_rkv"] = u_f * 3 * dd + n_f * 4 * vec
+        table["region_state"] = n_f * (10 + (3 if afd else 0)) * vec
     if st.get("routed"):  # ic_loop_step_fwd: the router's combine rides in the r/k/v kernel (per launch: e_f active
         # incoming edges -> message, key, precision rows; q_f destinations -> state and query rows in, M row out)
         table["region_rkv"] += (3 * st["e_f"] + 3 * st["q_f"]) * vec

@@ -385,6 +385,181 @@ __device__ __forceinline__ void region_rkv_body(const ic_region_args& a, float o
   }
 }
 
+// ---------------------------------------------------------------- r,k,v for MANY streams per region
+// With >= 32 streams a workgroup of k_region_rkv walks several active streams of its region one after the
+// other, each with its six reductions AND the state update on two lanes of every wave (R=512, k=32, S=64:
+// 0.42 of the HBM peak against 0.53 at S=8).  Split as in the backward: k_region_rkvG streams the weights and
+// leaves the raw r / k / v pre-activations of a batch of streams (input rows requested together), and
+// k_region_state finishes every active row elementwise (float4 lanes: sigmoid, time rotation, decay
+// fast-forward, WKV / AFD update).  Same dot products, same per-channel arithmetic: bit-identical.
+template <int DCH, int PP, int NSB>
+__global__ __launch_bounds__(256) void k_region_rkvG(ic_region_args a) {
+  const int r = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = a.d;
+  const int row0 = blockIdx.x * (8 * PP) + wave * (2 * PP);
+  if (row0 >= d) return;
+  const size_t dd = (size_t)d * d;
+  const int nz = gridDim.z;
+  RowFrag<DCH> wr[2 * PP], wk[2 * PP], wv[2 * PP];
+  bool loaded = false;
+  for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+    const int sl = sc + lane * nz;
+    unsigned long long act = __ballot(sl < a.S && a.mask[sl * a.R + r] != 0);
+    if (!act) continue;
+    if (!loaded) {  // (wave-uniform)
+      const float* Wr = a.W + (size_t)r * 4 * dd;
+#pragma unroll
+      for (int i = 0; i < 2 * PP; ++i) {
+        if (row0 + i < d) {
+          load_row(wr[i], Wr + (size_t)(row0 + i) * d, d, lane);
+          load_row(wk[i], Wr + dd + (size_t)(row0 + i) * d, d, lane);
+          load_row(wv[i], Wr + 2 * dd + (size_t)(row0 + i) * d, d, lane);
+        } else {
+          zero_frag(wr[i]); zero_frag(wk[i]); zero_frag(wv[i]);
+        }
+      }
+      loaded = true;
+    }
+    while (act) {
+      int srow[NSB];
+      RowFrag<DCH> xv[NSB];
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) {
+        srow[u] = -1;
+        zero_frag(xv[u]);
+        if (act) {
+          const int s = sc + (__ffsll((long long)act) - 1) * nz;
+          act &= act - 1;
+          srow[u] = s * a.R + r;
+          load_row(xv[u], a.x + (size_t)srow[u] * d, d, lane);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) {
+        if (srow[u] < 0) continue;  // wave-uniform
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+          const float pr0 = wave_sum(dot_frag(wr[2 * p], xv[u])), pr1 = wave_sum(dot_frag(wr[2 * p + 1], xv[u]));
+          const float pk0 = wave_sum(dot_frag(wk[2 * p], xv[u])), pk1 = wave_sum(dot_frag(wk[2 * p + 1], xv[u]));
+          const float pv0 = wave_sum(dot_frag(wv[2 * p], xv[u])), pv1 = wave_sum(dot_frag(wv[2 * p + 1], xv[u]));
+          const int ch = row0 + 2 * p + lane;
+          if (lane < 2 && ch < d) {
+            const size_t idx = (size_t)srow[u] * d + ch;
+            a.r_s[idx] = lane ? pr1 : pr0;
+            a.k_s[idx] = lane ? pk1 : pk0;
+            a.v_s[idx] = lane ? pv1 : pv0;
+          }
+        }
+      }
+    }
+  }
+}
+
+struct StateOut {
+  float rr, vv, y, num, den, var, sterm;
+};
+// one channel of region.py:186-216 (the arithmetic of k_region_rkv's lanes 0/1); vv is already rotated
+__device__ __forceinline__ StateOut state_one(bool afd, float steps, float rate, float pn, float on, float pr, float kk,
+                                              float vv, float num_in, float den_in, float var_in) {
+  StateOut o;
+  o.rr = ic_sigmoid(pr);
+  o.vv = vv;
+  o.var = o.sterm = 0.f;
+  const float lam = fmaxf(expf(rate * steps), IC_EPS_DIV);  // region.py:97-98
+  const float numd = num_in * lam, dend = den_in * lam;     // region.py:131-133
+  const float w = expf(fminf(kk, IC_MAX_EXP));              // region.py:190
+  if (afd) {  // region.py:192-212
+    const float vard = var_in * (lam * lam) + pn * steps;  // region.py:135
+    const float prd = numd / (dend + IC_EPS_DIV);
+    const float resid = w * vv - prd;
+    const float obs = expf(fminf(-kk, IC_MAX_EXP)) * on + IC_EPS_DIV;
+    float gain = vard / (vard + obs);
+    gain = fminf(fmaxf(gain, IC_EPS_DIV), 1.0f);  // fp32(1 - 1e-8) == 1
+    const float st = prd + gain * resid;
+    o.den = dend + w;
+    o.num = st * o.den;
+    o.var = (1.0f - gain) * vard;
+    o.sterm = (resid * resid) * (1.0f / (vard + obs));
+    o.y = o.rr * st;
+  } else {  // region.py:214-216
+    o.num = numd + w * vv;
+    o.den = dend + w;
+    o.y = o.rr * (o.num / (o.den + IC_EPS_DIV));
+  }
+  return o;
+}
+
+template <int DCH>
+__global__ __launch_bounds__(256) void k_region_state(ic_region_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  if (!a.mask[row]) return;
+  const int d = a.d, r = row % a.R;
+  const size_t off = (size_t)row * d;
+  const bool afd = a.flags & IC_F_AFD, vec = a.flags & IC_F_NOISE_VEC;
+  RowFrag<DCH> pr, pk, pv, num, den, var, rdv, pnv, onv;
+  load_row(pr, a.r_s + off, d, lane);
+  load_row(pk, a.k_s + off, d, lane);
+  load_row(pv, a.v_s + off, d, lane);
+  load_row(num, a.num + off, d, lane);
+  load_row(den, a.den + off, d, lane);
+  load_row(rdv, a.raw_decay + (size_t)r * d, d, lane);
+  zero_frag(var); zero_frag(pnv); zero_frag(onv);
+  float pn_s = 0.f, on_s = 0.f;
+  if (afd) {
+    load_row(var, a.var + off, d, lane);
+    if (vec) {
+      load_row(pnv, a.pn_param + (size_t)r * d, d, lane);
+      load_row(onv, a.on_param + (size_t)r * d, d, lane);
+    } else {
+      pn_s = ic_noise(a.pn_param[r]);
+      on_s = ic_noise(a.on_param[r]);
+    }
+  }
+  const float steps = (float)(a.dt[row] + 1);
+  RowFrag<DCH> o_r, o_v, o_y, o_num, o_den, o_var, o_st;
+#pragma unroll
+  for (int j = 0; j < DCH; ++j) {
+    const int ch0 = 256 * j + 4 * lane;
+    // time rotation of v (iron_rope.py:63-64): channels (2p, 2p+1) rotate together
+    float v0 = pv.v[j].x, v1 = pv.v[j].y, v2 = pv.v[j].z, v3 = pv.v[j].w;
+    if (ch0 < 2 * a.m_time) {
+      const float th = a.step_pos * a.W_time[ch0 >> 1];  // region.py:186
+      const float c = cosf(th), sn = sinf(th);
+      const float e = pv.v[j].x * c - pv.v[j].y * sn, o = pv.v[j].x * sn + pv.v[j].y * c;
+      v0 = e; v1 = o;
+    }
+    if (ch0 + 2 < 2 * a.m_time) {
+      const float th = a.step_pos * a.W_time[(ch0 >> 1) + 1];
+      const float c = cosf(th), sn = sinf(th);
+      const float e = pv.v[j].z * c - pv.v[j].w * sn, o = pv.v[j].z * sn + pv.v[j].w * c;
+      v2 = e; v3 = o;
+    }
+#define IC_ST(c, vrot) state_one(afd, steps, -ic_softplus(rdv.v[j].c), vec ? ic_noise(pnv.v[j].c) : pn_s, \
+                                 vec ? ic_noise(onv.v[j].c) : on_s, pr.v[j].c, pk.v[j].c, vrot, num.v[j].c, den.v[j].c, var.v[j].c)
+    const StateOut s0 = IC_ST(x, v0), s1 = IC_ST(y, v1), s2 = IC_ST(z, v2), s3 = IC_ST(w, v3);
+#undef IC_ST
+    o_r.v[j] = make_float4(s0.rr, s1.rr, s2.rr, s3.rr);
+    o_v.v[j] = make_float4(s0.vv, s1.vv, s2.vv, s3.vv);
+    o_y.v[j] = make_float4(s0.y, s1.y, s2.y, s3.y);
+    o_num.v[j] = make_float4(s0.num, s1.num, s2.num, s3.num);
+    o_den.v[j] = make_float4(s0.den, s1.den, s2.den, s3.den);
+    o_var.v[j] = make_float4(s0.var, s1.var, s2.var, s3.var);
+    o_st.v[j] = make_float4(s0.sterm, s1.sterm, s2.sterm, s3.sterm);
+  }
+  store_row(o_r, a.r_s + off, d, lane);
+  store_row(o_v, a.v_s + off, d, lane);
+  store_row(o_y, a.y + off, d, lane);
+  store_row(o_num, a.num_o + off, d, lane);
+  store_row(o_den, a.den_o + off, d, lane);
+  if (afd) {
+    store_row(o_var, a.var_o + off, d, lane);
+    store_row(o_st, a.sterm + off, d, lane);
+  }
+}
+
 template <int DCH, int PP, bool FUSE, bool CHAIN>
 __global__ __launch_bounds__(256) void k_region_rkv(ic_region_args a, float one_minus_alpha) {
   ic_router_args none;  // never read (ROUTED = false)
@@ -766,8 +941,17 @@ static int region_phase_launch(const ic_region_args* a, const ic_router_args* ra
   IC_DISPATCH_DCH(a->d, {                                                                                   \
     IC_TIMED(IC_KID_region_out, st, hipLaunchKernelGGL((k_region_out<DCH, PP>), gout, blk, 0, st, *a));     \
   })
+  // IC_FWD_SPLIT=0/1 forces the fused / the split r,k,v path (A/B timing; same results bit for bit)
+  static const int fsplit_env = [] { const char* e = getenv("IC_FWD_SPLIT"); return (e && e[0]) ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool fsplit = !chain && !fuse && !ra && rpb == 8 && (fsplit_env >= 0 ? fsplit_env == 1 : a->S / nz >= 32);
   if (ra) {
     IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkv_routed<1, 1>), gmat, blk, 0, st, *a, oma, *ra));
+  } else if (fsplit) {
+    IC_DISPATCH_DCH(a->d, {
+      IC_TIMED(IC_KID_region_pro, st, hipLaunchKernelGGL(k_region_pro<DCH>, grow, blk, 0, st, *a));
+      IC_TIMED(IC_KID_region_rkv, st, hipLaunchKernelGGL((k_region_rkvG<DCH, 1, (DCH <= 2 ? 4 : 2)>), gmat, blk, 0, st, *a));
+      IC_TIMED(IC_KID_region_state, st, hipLaunchKernelGGL(k_region_state<DCH>, grow, blk, 0, st, *a));
+    });
   } else if (rpb == 8) IC_RKV_LAUNCH(1);
   else if (rpb == 16) IC_RKV_LAUNCH(2);
   else IC_RKV_LAUNCH(4);

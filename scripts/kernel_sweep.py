@@ -122,7 +122,8 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
                 q_uniq = sum(int(torch.zeros(R, device=dev).index_add_(0, router.dst_idx, m.bool()[:, router.src_idx].any(0).float()).gt(0).sum())
                              for m in masks) / n_sets
                 pairs = sum(int(m.sum()) for m in masks) / n_sets
-                st = dict(u_f=uniq, n_f=pairs, u_b=uniq, n_b=pairs, e=e_uniq, ep=e_pairs, q=q_uniq, R=R, S=S, afd=False, prec=False)
+                st = dict(u_f=uniq, n_f=pairs, u_b=uniq, n_b=pairs, e=e_uniq, ep=e_pairs, q=q_uniq, R=R, S=S, afd=False, prec=False,
+                          fsplit=(os.environ.get("IC_FWD_SPLIT") or ("1" if S >= 32 else "0"))[0] != "0")
                 row = {"R": R, "S": S, "k": k, "d": d, "rotate": len(masks), "backward": backward,
                        "unique_regions": uniq, "unique_edges": e_uniq, "pairs": pairs, "edge_pairs": e_pairs,
                        "weights_MiB": {"regions": R * 4 * d * d * 4 / 2**20, "W_edge": router.E * d * d * 4 / 2**20},
@@ -140,7 +141,7 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
         torch.cuda.empty_cache()
 
 
-SWEEP_KERNELS = ("region_pro", "region_rkv", "region_out", "region_fin", "router_fwd", "region_out_bwd", "region_rkv_bwd",
+SWEEP_KERNELS = ("region_pro", "region_rkv", "region_state", "region_out", "region_fin", "router_fwd", "region_out_bwd", "region_rkv_bwd",
                  "region_mid_bwd", "region_pro_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_region", "wgrad_edge")
 
 

@@ -12,7 +12,7 @@ import sys
 
 # kernel function -> the library's kernel id (ic_common.h IcKid; bench.py reports by id).  k_front is the
 # gate + router-edge launch: id router_edge_fwd with precision routing (the bench config), router_fwd without.
-ALIAS = {"region_rkv_routed": "region_rkv", "router_fwd_ms": "router_fwd", "region_fin_chain": "region_fin",
+ALIAS = {"region_rkv_routed": "region_rkv", "region_rkvG": "region_rkv", "router_fwd_ms": "router_fwd", "region_fin_chain": "region_fin",
          "router_comb_bwd_serial": "router_comb_bwd", "region_rkvT_bwd": "region_rkv_bwd", "router_matT_bwd": "router_mat_bwd",
          "region_chan_bwd": "region_mid_bwd", "router_combine_serial": "router_combine",
          "gemv_multi": "gemv", "gemv_reg": "gemv", "gemv_chain1": "gemv", "heads": "token_rows",

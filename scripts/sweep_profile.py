@@ -14,7 +14,7 @@ import sys
 
 HBM_PEAK_GBS = 8000.0
 # kernel function -> the library's kernel id (ic_common.h IcKid)
-ALIAS = {"region_rkv_routed": "region_rkv", "router_fwd_ms": "router_fwd", "region_fin_chain": "region_fin",
+ALIAS = {"region_rkv_routed": "region_rkv", "region_rkvG": "region_rkv", "router_fwd_ms": "router_fwd", "region_fin_chain": "region_fin",
          "router_comb_bwd_serial": "router_comb_bwd", "region_rkvT_bwd": "region_rkv_bwd", "router_matT_bwd": "router_mat_bwd",
          "region_chan_bwd": "region_mid_bwd", "router_combine_serial": "router_combine"}
 

@@ -142,6 +142,41 @@ def test_region_phase_sweep_variants_vs_oracle(R, S, k, monkeypatch):
         PL.flush(tag)
 
 
+@pytest.mark.parametrize("d,afd,rt,noise", [(256, False, False, "scalar"), (256, True, True, "vector"),
+                                            (128, True, False, "scalar"), (512, True, True, "scalar")])
+def test_region_forward_many_streams_equals_stream_groups_bitwise(d, afd, rt, noise):
+    """From 32 streams per launch the library takes the split forward (k_region_rkvG + k_region_state) instead of
+    the fused k_region_rkv: same dot products and per-channel arithmetic, so 64 streams in ONE launch equal the
+    same streams in eight launches of 8 (the fused kernel, itself pinned to the oracle above) bit for bit.
+    IC_FWD_SPLIT=1 sends every non-chained launch of a process down the split path (run the suite under it)."""
+    R, S, k, G = 48, 64, 6, 8
+    seed = 7700 + d
+    bank, cells, P = build_bank(R, d, afd, rt, noise, seed)
+    st = {"num": gi.det(seed + 10, S, R, d, kind="rand"), "den": gi.det(seed + 11, S, R, d, kind="rand", shift=0.5),
+          "var": gi.det(seed + 12, S, R, d, kind="rand", scale=0.2), "pred": gi.det(seed + 13, S, R, d, scale=0.1),
+          "radius": gi.det(seed + 14, S, R, kind="rand", shift=0.5), "radius_var": gi.det(seed + 15, S, R, kind="rand", scale=0.2),
+          "surprise": torch.zeros(S, R), "dt": (gi.det(seed + 17, S, R, kind="rand") * 8).to(torch.int32)}
+    M, sensor = gi.det(seed + 18, S, R, d).to(DEV), gi.det(seed + 19, S, d).to(DEV)
+    mask = sparse_mask(seed + 20, S, R, k).to(torch.uint8).to(DEV)
+    mask[5] = 0  # a stream with nothing to do
+    nin = gi.det(seed + 21, d, scale=0.1, shift=1.0).to(DEV)
+    keys = ("num", "den", "var", "pred", "radius", "radius_var", "surprise", "dt")
+
+    def run(lo, hi):
+        bank.reset_state(torch.device(DEV), hi - lo)
+        for k_ in keys:
+            setattr(bank, k_, st[k_][lo:hi].clone().to(DEV))
+        with torch.no_grad():
+            H = bank.phase(M[lo:hi], sensor[lo:hi], nin, mask[lo:hi], 0.5)
+        return [H.clone()] + [getattr(bank, k_).clone() for k_ in keys]
+
+    whole = run(0, S)
+    parts = [run(lo, lo + G) for lo in range(0, S, G)]
+    assert float(whole[0].abs().sum()) > 0
+    for i, name in enumerate(("H",) + keys):
+        assert torch.equal(whole[i], torch.cat([p_[i] for p_ in parts])), name
+
+
 @pytest.mark.parametrize("R,S,k", [(64, 1, 8), (64, 8, 8), (512, 1, 32), (512, 8, 32)])
 @pytest.mark.parametrize("prec", [False, True], ids=["plain", "precision"])
 def test_router_sweep_sizes_vs_oracle(R, S, k, prec):
@@ -212,6 +247,30 @@ def test_router_sweep_sizes_vs_oracle(R, S, k, prec):
               torch.stack([P["query_W"][r].grad if P["query_W"][r].grad is not None else zq for r in range(R)]).reshape(1, -1),
               what="g.query", tol=1e-4)
     PL.flush(tag)
+
+
+@pytest.mark.parametrize("d", [256, 512, 48])
+def test_router_forward_many_streams_equals_stream_groups_bitwise(d):
+    """The per-edge router forward walks the streams 64 at a time, each edge's active streams from one ballot:
+    64 + 6 streams in one launch equal the same streams in launches of 8 bit for bit (products and accumulation
+    order do not depend on how many streams share a launch)."""
+    from ironcortex_amd.gate import Router
+    from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
+    R, S, k, G = 90, 70, 12, 8
+    seed = 7800 + d
+    router = Router(hex_neighbors(R), d, R).to(DEV)
+    coords = hex_axial_coords(R).to(DEV)
+    with torch.no_grad():
+        router._flat.stacked("W").copy_(gi.det(seed + 1, router.E, d, d, kind="xavier"))
+    mask = sparse_mask(seed, S, R, k)
+    mask[3] = False
+    H = (gi.det(seed + 8, S, R, d) * mask.unsqueeze(-1)).to(DEV)
+    mg = mask.to(torch.uint8).to(DEV)
+    with torch.no_grad():
+        whole = router.route(H, mg, coords).clone()
+        parts = torch.cat([router.route(H[lo:lo + G], mg[lo:lo + G], coords).clone() for lo in range(0, S, G)])
+    assert float(whole.abs().sum()) > 0
+    assert torch.equal(whole, parts)
 
 
 @pytest.mark.parametrize("R,S,d", [(36, 4, 256), (64, 8, 256), (10, 3, 48)])
