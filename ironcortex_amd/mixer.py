@@ -12,6 +12,7 @@ from __future__ import annotations
 import math
 from typing import List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -240,27 +241,42 @@ class LocalTokenMixer(FastAttrs, nn.Module):
             self.last_energy = self.attn.last_attn_energy.detach()
             self.last_energy_b = self.attn.last_attn_energy_b
             return pooled
-        rows, n_max = [], 0
-        focus_host = focus_mask.tolist() if focus_mask is not None else [None] * B  # one host read
-        for b in range(B):
-            anchors = self.build_anchors(T, focus_host[b])
-            rows.append(anchors)
-            n_max = max(n_max, len(anchors))
-        ragged = any(len(a) != n_max for a in rows)
+        # anchors of all samples laid out on the host (one read of the focus bits, one upload): the stride
+        # anchors are the same for every row, then (span start, kind 1), (span last, kind 2) per focus span
+        base = [i for S in (128, 32) for i in range(S // 2, T, S)]
+        nb = len(base)
+        if focus_mask is not None:
+            fh = focus_mask.detach().cpu().numpy().astype(np.int8)
+            edge = np.diff(np.pad(fh, ((0, 0), (1, 1))), axis=1)  # +1 at a span's start, -1 one past its end
+            rs, starts = np.nonzero(edge == 1)
+            _re, ends = np.nonzero(edge == -1)  # row-major: the j-th end belongs to the j-th start
+            n_span = np.bincount(rs, minlength=B)
+        else:
+            rs = starts = ends = np.zeros(0, dtype=np.int64)
+            n_span = np.zeros(B, dtype=np.int64)
+        lens = nb + 2 * n_span
+        n_max = int(lens.max()) if B else 0
+        ragged = bool((lens != n_max).any())
         Ta = T + n_max
         X = torch.zeros(B, Ta, d, device=dev)
         C = torch.zeros(B, Ta, 2, device=dev)
         UM = torch.zeros(B, Ta, dtype=torch.bool, device=dev)
         X[:, :T], C[:, :T], UM[:, :T] = tok_emb, pos_coords, focus_mask
-        for b, anchors in enumerate(rows):
-            if anchors:
-                a_idx = torch.tensor([a[0] for a in anchors], dtype=torch.long, device=dev)
-                a_kind = torch.tensor([a[1] for a in anchors], dtype=torch.long, device=dev)
-                n = len(anchors)
-                X[b, T:T + n] = self.anch_embed[a_kind]
-                pos = a_idx.to(torch.float32)
-                C[b, T:T + n] = torch.stack([pos, pos / (T + EPS_DIV)], dim=-1)
-        valid_len = torch.tensor([T + len(a) for a in rows], device=dev) if ragged else None
+        if n_max > 0:
+            packed = np.zeros((3, B, n_max), dtype=np.int64)  # position, kind, valid
+            packed[0, :, :nb] = np.asarray(base, dtype=np.int64)
+            packed[2, :, :nb] = 1
+            if len(rs):
+                j = np.arange(len(rs)) - np.concatenate([[0], np.cumsum(n_span)])[rs]  # span number within its row
+                col = nb + 2 * j
+                packed[0, rs, col], packed[1, rs, col], packed[2, rs, col] = starts, 1, 1
+                packed[0, rs, col + 1], packed[1, rs, col + 1], packed[2, rs, col + 1] = np.maximum(starts, ends - 1), 2, 1
+            pk = torch.from_numpy(packed).to(dev)
+            ok = pk[2].to(torch.float32)
+            posf = pk[0].to(torch.float32)
+            X[:, T:] = self.anch_embed[pk[1]] * ok.unsqueeze(-1)
+            C[:, T:] = torch.stack([posf, posf / (T + EPS_DIV)], dim=-1) * ok.unsqueeze(-1)
+        valid_len = torch.from_numpy(T + lens).to(dev) if ragged else None
         Y = self.attn(X, coords=C, update_mask=UM, context_mask=None, dropout=use_dropout, valid_len=valid_len)
         pooled = masked_mean(Y[:, :T, :], focus_mask)
         self.last_energy = self.attn.last_attn_energy.detach()
