@@ -473,6 +473,44 @@ int ic_prof_read(int kid, int64_t* launches, double* total_ms);
  * device-side unit counts (bench.py). */
 int ic_prof_bytes_read(int kid, int64_t* launches, double* bytes);
 
+/* ---------------------------------------------------------------- token-mixer attention
+ * Replaces the score / softmax / statistics / value product of reference iron_rope.py:201-235
+ * (IronRoPESelfAttention.forward: q k^T / sqrt(hd) + relative Fourier bias, key padding, softmax, att @ v and the
+ * attention-energy statistic -mean log(att + eps)) and of attention/adaptive_filter_attention.py:60-88,100-117
+ * (AdaptiveFilterAttention._exact_path without a mask: scores * exp(-alpha |i-j| dt), softmax, energy and entropy
+ * statistics).  The caller folds 1/sqrt(hd), the rotary rotation and the rank-2m Fourier features of the bias
+ * into the q / k rows (ironcortex_amd/mixer.py), so a score is a plain dot product of dqk columns.
+ * fp32 MFMA, two passes over the keys, no [T,T] tensor in memory. */
+typedef struct ic_attn_args {
+  int B, H, T;              /* batch, heads, positions */
+  int dqk, dv;              /* columns of a q / k row and of a v row; (dqk, dv) in {(32,32), (64,64), (128,128),
+                               (96,32), (128,64), (192,128)}: head width alone or + 64 bias columns (zero-pad others) */
+  const float* q;           /* [B,H,T,dqk] */
+  const float* k;           /* [B,H,T,dqk] */
+  const float* v;           /* [B,H,T,dv] */
+  const int32_t* valid_len; /* [B] or NULL: keys >= valid_len[b] are padding (probability 0, left out of stats) */
+  const float* alpha;       /* NULL, or one device scalar: score(i,j) = q_i.k_j * exp(-alpha * |i-j| * lag_dt) */
+  float lag_dt;
+  float eps_log;            /* the eps of log(p + eps) in the statistics (constants.py EPS_LOG) */
+  float* out;               /* [B,H,T,dv]  softmax(scores) @ v */
+  float* lse;               /* [B,H,T]     log-sum-exp of each query's scores (saved for the backward) */
+  float* stats;             /* [B,H,T,2]   sum_k log(p+eps), sum_k p*log(p+eps) over the valid keys of each query */
+} ic_attn_args;
+int ic_attn_fwd(const ic_attn_args* a, ic_stream_t stream);
+/* Backward of ic_attn_fwd's `out` (the statistics carry no gradient, as in the reference: computed under
+ * no_grad / detached).  Every dq / dk / dv row is written by one workgroup, d alpha leaves as per-workgroup
+ * partial sums: no float atomics, run-to-run identical. */
+typedef struct ic_attn_bwd_args {
+  ic_attn_args f;           /* the forward's arguments (out, lse as it wrote them; stats unused) */
+  const float* dout;        /* [B,H,T,dv] */
+  const float* drow;        /* [B,H,T] = sum over dv of dout * out */
+  float* dq;                /* [B,H,T,dqk] */
+  float* dk;                /* [B,H,T,dqk] */
+  float* dv;                /* [B,H,T,dv] */
+  float* dalpha_part;       /* [B*H*ceil(T/128)] partial sums of d loss / d alpha (needed iff f.alpha) */
+} ic_attn_bwd_args;
+int ic_attn_bwd(const ic_attn_bwd_args* b, ic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -567,6 +567,66 @@ class GoodnessFn(torch.autograd.Function):
         return gH.view(ctx.shape)
 
 
+ATTN_SHAPES = ((32, 32), (64, 64), (128, 128), (96, 32), (128, 64), (192, 128))  # (dqk, dv) the library has kernels for
+
+
+def _pad_cols(x: torch.Tensor, w: int) -> torch.Tensor:
+    return x if x.shape[-1] == w else torch.nn.functional.pad(x, (0, w - x.shape[-1]))
+
+
+class AttnFn(torch.autograd.Function):
+    """softmax(q k^T [* exp(-alpha |i-j| dt)]) v for [B,H,T,*] rows on the matrix cores (ic_attn_fwd / ic_attn_bwd;
+    iron_rope.py:201-235, adaptive_filter_attention.py:60-88): no [T,T] tensor.  Returns (out, stats) with
+    stats[b,h,q] = (sum_k log(p+eps), sum_k p log(p+eps)) over the valid keys (no gradient, as in the reference)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, valid_len, alpha, lag_dt, eps_log):
+        B, H, T, dqk = q.shape
+        dv = v.shape[-1]
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = torch.empty(B, H, T, dv, device=q.device)
+        lse = torch.empty(B, H, T, device=q.device)
+        stats = torch.empty(B, H, T, 2, device=q.device)
+        al = None if alpha is None else alpha.detach().reshape(1).contiguous()
+        a = new("ic_attn_args", B=B, H=H, T=T, dqk=dqk, dv=dv, q=q, k=k, v=v, valid_len=valid_len, alpha=al,
+                lag_dt=float(lag_dt), eps_log=float(eps_log), out=out, lse=lse, stats=stats)
+        _call("ic_attn_fwd", a)
+        ctx.save_for_backward(q, k, v, out, lse, valid_len, al)
+        ctx.cfg = (float(lag_dt), float(eps_log), alpha is not None and alpha.requires_grad)
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, gout, _gstats):
+        q, k, v, out, lse, valid_len, al = ctx.saved_tensors
+        lag_dt, eps_log, want_alpha = ctx.cfg
+        B, H, T, dqk = q.shape
+        dv = v.shape[-1]
+        gout = gout.contiguous()
+        drow = (gout * out).sum(-1)
+        dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        part = torch.empty(B * H * ((T + 127) // 128), device=q.device) if al is not None else None
+        f = new("ic_attn_args", B=B, H=H, T=T, dqk=dqk, dv=dv, q=q, k=k, v=v, valid_len=valid_len, alpha=al,
+                lag_dt=lag_dt, eps_log=eps_log, out=out, lse=lse, stats=None)
+        b = new("ic_attn_bwd_args", f=f, dout=gout, drow=drow, dq=dq, dk=dk, dv=dvv, dalpha_part=part)
+        _call("ic_attn_bwd", b)
+        galpha = part.sum().reshape(()) if want_alpha else None
+        return dq, dk, dvv, None, galpha, None, None
+
+
+def attention(q, k, v, valid_len=None, alpha=None, lag_dt: float = 1.0, eps_log: float = 1e-9):
+    """AttnFn with the rows zero-padded to a (dqk, dv) pair the library has kernels for (zero columns change neither
+    the scores nor the kept output columns)."""
+    dqk, dv = q.shape[-1], v.shape[-1]
+    fit = [(a, b) for a, b in ATTN_SHAPES if a >= dqk and b >= dv]
+    if not fit:
+        raise RuntimeError(f"ic_attn: no kernel for q/k rows of {dqk} and v rows of {dv} columns")
+    pa, pb = min(fit, key=lambda s: s[0] * 2 + s[1])
+    vl = None if valid_len is None else valid_len.to(torch.int32).contiguous()
+    out, stats = AttnFn.apply(_pad_cols(q, pa), _pad_cols(k, pa), _pad_cols(v, pb), vl, alpha, lag_dt, eps_log)
+    return (out if pb == dv else out[..., :dv]), stats
+
+
 def hebbian_rank1(W: torch.Tensor, dst_of_edge: torch.Tensor, src: torch.Tensor, widx: torch.Tensor,
                   coef: torch.Tensor, H: torch.Tensor) -> None:
     """In-place W[widx[e]] += sum_b coef[b,e] * outer(H[b,dst_e], H[b,src_e])."""

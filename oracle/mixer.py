@@ -1,14 +1,16 @@
-"""Token mixer that pools the focused positions into the sensor vector.  Parameter
-names follow reference iron_rope.py:100-374 and attention/adaptive_filter_attention.py so checkpoints load
-unchanged.  The attention core (scores, softmax, statistics, value product and their backward) runs on the
-library's fp32-MFMA kernels (ic_attn_fwd / ic_attn_bwd, csrc/attn_mfma.hip): no [B,H,T,T] tensor exists.
+"""TEST INFRASTRUCTURE ONLY (oracle): CPU restatement of the reference's token mixer in plain PyTorch --
+iron_rope.py:16-97 (frequency bank, rotary pairs, Fourier relative bias), :100-251 (IronRoPESelfAttention),
+:254-374 (LocalTokenMixer with anchor tokens) and attention/adaptive_filter_attention.py:8-127 -- with the
+[B,H,T,T] score / probability tensors in memory as the reference has them.  oracle/model.py builds its whole-model
+oracle on it; the product's mixer (ironcortex_amd/mixer.py) runs the attention core on the HIP library instead.
+Pinned by the reference's own outputs through tests/golden/model_*.npz (logits, traces and gradients of the real
+reference run through this mixer: tests/test_oracle_model.py).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it.
 
-How the reference's arithmetic reaches that kernel without changing results:
-  * the Fourier relative bias b(p_q - p_k) is a rank-2m feature product (cos/sin addition theorem), so it
-    rides as 2m extra q / k columns instead of a [B,T,T,m] tensor; 1/sqrt(hd) is folded into q;
-  * no [1,1,max_T,max_T] mask buffer for the bidirectional case; padded anchor rows are a per-sample key count.
-Options the mixer never uses (causal, an explicit context mask, attention dropout > 0, an AFA mask) keep the
-plain PyTorch formulation of the same arithmetic (`*_torch`), which is also the tests' fp32 reference."""
+Differences from the reference's text that do not change results: the Fourier relative bias b(p_q - p_k) is
+evaluated as a rank-2m feature product (cos/sin addition theorem) instead of a [B,T,T,m] tensor; no
+[1,1,max_T,max_T] mask buffer for the bidirectional case; anchors of a batch are laid out in one pass with a
+per-sample valid length (every sample sees exactly what a batch-of-one call would)."""
 from __future__ import annotations
 
 import math
@@ -19,9 +21,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .constants import EPS_DIV, EPS_LOG, MAX_EXP
-from .hip import ops
-from .utils import FastAttrs, extract_spans, init_weights, masked_mean
+from ironcortex_amd.constants import EPS_DIV, EPS_LOG, MAX_EXP
+from ironcortex_amd.utils import FastAttrs, extract_spans, init_weights, masked_mean
 
 
 def make_freq_bank(m: int, d_coord: int, kind: str = "log", base: float = 10000.0, sigma: float = 1.0,
@@ -48,23 +49,6 @@ def rope_rotate_pairs(x: torch.Tensor, cos_th: torch.Tensor, sin_th: torch.Tenso
     even, odd = head[..., 0::2], head[..., 1::2]
     rot = torch.stack((even * cos_th - odd * sin_th, even * sin_th + odd * cos_th), dim=-1)
     return torch.cat([rot.flatten(-2), tail], dim=-1)
-
-
-def fourier_features(p: torch.Tensor, W, beta_cos, beta_sin, scale: float = 1.0):
-    """(left, right) with left[q] . right[k] = scale * sum_m cos(S)beta_cos + sin(S)beta_sin, S = (p_q - p_k) W^T
-    (iron_rope.py:69-97): left [B,T,2m] (headwise betas: [B,H,T,2m]), right [B,T,2m]."""
-    if W.shape[1] != p.shape[-1]:
-        W = W.expand(W.shape[0], p.shape[-1])
-    a = p @ W.T
-    c, s = torch.cos(a), torch.sin(a)
-    right = torch.cat([c, s], dim=-1)
-    if beta_cos.dim() == 2:
-        bc, bs = beta_cos[None, :, None, :], beta_sin[None, :, None, :]
-        c, s = c.unsqueeze(1), s.unsqueeze(1)
-    else:
-        bc, bs = beta_cos, beta_sin
-    left = torch.cat([c * bc + s * bs, s * bc - c * bs], dim=-1) * scale
-    return left, right
 
 
 def relative_fourier_bias(p_q, p_k, W, beta_cos, beta_sin, scale: float = 1.0) -> torch.Tensor:
@@ -136,50 +120,12 @@ class IronRoPESelfAttention(nn.Module):
             theta = coords @ self.W_rope.T
             c, s = torch.cos(theta).unsqueeze(1), torch.sin(theta).unsqueeze(1)
             q, k = rope_rotate_pairs(q, c, s, self.rope_m), rope_rotate_pairs(k, c, s, self.rope_m)
-        plain = not self.causal and context_mask is None and not (dropout and self.training and self.adrop.p > 0)
-        if plain:  # the library's kernels
-            y = self._attend_hip(q, k, v, coords, valid_len)
-        else:
-            y = self._attend_torch(q, k, v, coords, context_mask, valid_len, dropout)
-        y = self.c_proj(y.transpose(1, 2).contiguous().view(B, T, C))
-        if dropout:
-            y = self.rdrop(y)
-        if update_mask is not None:
-            return x + y * update_mask.unsqueeze(-1).to(y.dtype)
-        return x + y
-
-    def _attend_hip(self, q, k, v, coords, valid_len):
-        """iron_rope.py:201-235 through ic_attn_fwd: bias features appended to the q / k rows."""
-        B, H, T, hd = q.shape
-        q = q * (1.0 / math.sqrt(self.head_dim))
-        if self.fb_m > 0:
-            left, right = fourier_features(coords, self.W_fb, self.beta_cos, self.beta_sin, self.fb_scale)
-            left = left if left.dim() == 4 else left.unsqueeze(1)
-            q = torch.cat([q, left.expand(B, H, T, -1)], dim=-1)
-            k = torch.cat([k, right.unsqueeze(1).expand(B, H, T, -1)], dim=-1)
-        out, stats = ops.attention(q, k, v, valid_len=valid_len, eps_log=EPS_LOG)
-        s0 = stats[..., 0]
-        if valid_len is None:
-            self.last_attn_energy_b = -s0.sum(dim=(1, 2)) / float(H * T * T)
-            self.last_attn_energy = self.last_attn_energy_b.mean()
-        else:  # valid queries only; the kernel already left the padding keys out
-            vq = (torch.arange(T, device=q.device).unsqueeze(0) < valid_len.unsqueeze(1)).to(s0.dtype)
-            cnt = valid_len.to(s0.dtype).pow(2) * H
-            self.last_attn_energy_b = -(s0 * vq.unsqueeze(1)).sum(dim=(1, 2)) / cnt
-            self.last_attn_energy = self.last_attn_energy_b.mean()
-        return out
-
-    def _attend_torch(self, q, k, v, coords, context_mask, valid_len, dropout):
-        """The same arithmetic with the [B,H,T,T] tensors in memory (options the kernels do not take; the
-        tests' fp32 reference)."""
-        T = q.shape[2]
         att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(self.head_dim))
         if self.fb_m > 0:
             att = att + relative_fourier_bias(coords, coords, self.W_fb, self.beta_cos, self.beta_sin, self.fb_scale)
         if self.causal:
             keep = torch.ones(T, T, dtype=torch.bool, device=x.device).tril()
             att = att.masked_fill(~keep, float("-inf"))
-        x = q  # (device / dtype of the masks below)
         valid = None
         if valid_len is not None:
             valid = torch.arange(T, device=x.device).unsqueeze(0) < valid_len.unsqueeze(1)  # [B,T]
@@ -198,7 +144,12 @@ class IronRoPESelfAttention(nn.Module):
             self.last_attn_energy = self.last_attn_energy_b.mean() if valid is not None else -logp.mean()
         if dropout:
             att = self.adrop(att)
-        return att @ v
+        y = self.c_proj((att @ v).transpose(1, 2).contiguous().view(B, T, C))
+        if dropout:
+            y = self.rdrop(y)
+        if update_mask is not None:
+            return x + y * update_mask.unsqueeze(-1).to(y.dtype)
+        return x + y
 
 
 class AdaptiveFilterAttention(FastAttrs, nn.Module):
@@ -221,26 +172,6 @@ class AdaptiveFilterAttention(FastAttrs, nn.Module):
         self.last_attn_entropy = torch.tensor(0.0)
 
     def _attend(self, q, k, v, mask):
-        if mask is None:
-            return self._attend_hip(q, k, v)
-        return self._attend_torch(q, k, v, mask)
-
-    def _attend_hip(self, q, k, v):
-        """adaptive_filter_attention.py:60-88 through ic_attn_fwd (scores * exp(-alpha |i-j| dt) in the kernel)."""
-        B, H, T, _ = q.shape
-        out, stats = ops.attention(q * self.scale, k, v, alpha=self.alpha, lag_dt=float(self.dt), eps_log=EPS_LOG)
-        with torch.no_grad():
-            lag = torch.arange(1, T, device=q.device, dtype=torch.float32)
-            w = torch.exp(-2.0 * self.alpha.detach() * lag * self.dt) * (T - lag)  # ||decay||_F^2 = T + 2 sum_lag (T-lag) e^(-2 a lag dt)
-            self.last_kernel_norm = (T + 2.0 * w.sum()).sqrt()
-            s0, s1 = stats[..., 0], stats[..., 1]
-            self.last_attn_energy_b = -s0.sum(dim=(1, 2)) / float(H * T * T)
-            self.last_attn_entropy_b = -s1.sum(dim=(1, 2)) / float(H * T)
-            self.last_attn_energy = self.last_attn_energy_b.mean()
-            self.last_attn_entropy = self.last_attn_entropy_b.mean()
-        return out
-
-    def _attend_torch(self, q, k, v, mask):
         T = q.size(-2)
         idx = torch.arange(T, device=q.device, dtype=torch.float32)
         lag = (idx.view(T, 1) - idx.view(1, T)).abs()
@@ -347,10 +278,7 @@ class LocalTokenMixer(FastAttrs, nn.Module):
             pk = torch.from_numpy(packed).to(dev)
             ok = pk[2].to(torch.float32)
             posf = pk[0].to(torch.float32)
-            # (a [*,3] one-hot product, not anch_embed[kind]: the gather's backward is an index_put over three
-            # rows shared by every anchor of the batch -- 0.6 ms at T=256, 2.1 ms at T=1024 of serialised adds)
-            kinds = F.one_hot(pk[1], 3).to(torch.float32) * ok.unsqueeze(-1)
-            X[:, T:] = kinds @ self.anch_embed
+            X[:, T:] = self.anch_embed[pk[1]] * ok.unsqueeze(-1)
             C[:, T:] = torch.stack([posf, posf / (T + EPS_DIV)], dim=-1) * ok.unsqueeze(-1)
         valid_len = torch.from_numpy(T + lens).to(dev) if ragged else None
         Y = self.attn(X, coords=C, update_mask=UM, context_mask=None, dropout=use_dropout, valid_len=valid_len)

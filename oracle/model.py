@@ -4,8 +4,9 @@ TEST INFRASTRUCTURE ONLY (see oracle/hotpath.py).  The hot path (gate, router, r
 KWTA, RMSNorm, FF goodness, Hebbian nudges) is the oracle restatement, executed the way the
 reference executes it: one Python call per region per inner step, the token mixer recomputed
 at every inner step (reference model.py:206-321), a Python loop over regions in the FF loss
-(training.py:120-156).  The parts OUTSIDE the §8 hot path (token mixer, heads, energy verifier,
-corruptions) are shared with the product package: they are plain PyTorch either way.
+(training.py:120-156).  The token mixer is the oracle's own plain-PyTorch restatement (oracle/mixer.py; the
+product runs its attention core on the HIP library).  The remaining parts OUTSIDE the §8 hot path (heads,
+energy verifier, corruptions) are shared with the product package: they are plain PyTorch either way.
 State-dict keys equal the reference's, so reference fixtures load into this model unchanged.
 """
 from __future__ import annotations
@@ -22,12 +23,12 @@ from ironcortex_amd.config import CortexConfig
 from ironcortex_amd.corruptions import corrupt
 from ironcortex_amd.energy import EnergyVerifierHead, ff_energy_loss
 from ironcortex_amd.heads import CriticHead, PlannerHead, RTDHead, TokenHead_MFS
-from ironcortex_amd.mixer import LocalTokenMixer
 from ironcortex_amd.sdr import SparseTokenEncoder
 from ironcortex_amd.training import LossWeights
 from ironcortex_amd.utils import RegionFFState, context_logprob, schedule_burst, should_halt, uncertainty_from_logits
 
 from . import hotpath as O
+from .mixer import LocalTokenMixer
 
 
 def _xavier(m):

@@ -40,8 +40,26 @@ def main():
                 step()
             e1.record()
             torch.cuda.synchronize()
-            print(json.dumps({"config": name, "T": T, "N": N, "fwd_bwd_ms": e0.elapsed_time(e1) / it,
-                              "peak_mem_MB": torch.cuda.max_memory_allocated() / 2**20}), flush=True)
+            row = {"config": name, "T": T, "N": N, "fwd_bwd_ms": e0.elapsed_time(e1) / it,
+                   "peak_mem_MB": torch.cuda.max_memory_allocated() / 2**20}
+            # the attention kernels alone (HIP events around each launch; a separate, untimed pass)
+            from ironcortex_amd import hip
+            hip.prof_enable(True)
+            hip.prof_read()
+            for _ in range(it):
+                step()
+            pr = hip.prof_read()
+            hip.prof_enable(False)
+            Ta = T + (0 if cfg.enable_afa_attention else 2 * sum(len(range(S // 2, T, S)) for S in (128, 32)) // 2 + 8)
+            hd = cfg.d // 4
+            dqk = hd if cfg.enable_afa_attention else hd + 64
+            flop = {"attn_fwd": 2 * (2 * dqk + hd), "attn_bwd_kv": 2 * (2 * dqk + 2 * hd), "attn_bwd_q": 2 * (2 * dqk + hd)}
+            for kname, (n, ms) in pr.items():
+                if kname.startswith("attn"):
+                    us = 1e3 * ms / n
+                    row[kname + "_us"] = round(us, 1)
+                    row[kname + "_TFLOPs"] = round(flop[kname] * N * 4 * Ta * Ta / (us * 1e-6) / 1e12, 1)
+            print(json.dumps(row), flush=True)
             del model
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats()
