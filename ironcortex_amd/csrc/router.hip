@@ -89,50 +89,91 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
   const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
   if (row0 >= d) return;
   const size_t dd = (size_t)d * d;
+  // Streams z, z + nz, ... of this grid slice are tested 64 at a time (one mask byte per lane, one ballot) and
+  // only the active ones visited, their sender rows requested two at a time.  (Asking for every stream's mask
+  // byte in turn cost a dependent memory round trip per stream: 2.2 ms at R=512, k=32, S=64.)
+  const int nz = gridDim.z;
   if (y < a.E) {
     const int e = y, src = a.src[e];
-    const int nz = gridDim.z;  // streams z, z + nz, ... (gridDim.z > 1: many streams, see ic_front_launch)
-    bool any = false;  // lanes test 64 streams per round trip: idle workgroups leave quickly
-    for (int sc = blockIdx.z; sc < a.S && !any; sc += 64 * nz)
-      any = __ballot(sc + lane * nz < a.S && prev_on(a, sc + lane * nz, src)) != 0;
-    if (!any) return;
-    const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
-    const float* K = a.key_W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
-    RowFrag<DCH> w0, w1, k0, k1, h;
-    load_row(w0, W, d, lane);
-    load_row(w1, W + d, d, lane);
-    load_row(k0, K, d, lane);
-    load_row(k1, K + d, d, lane);
-    const float bias = a.ebias[e];
-    for (int s = blockIdx.z; s < a.S; s += nz) {
-      if (!prev_on(a, s, src)) continue;
-      load_row(h, h_row(a, s, src), d, lane);
-      const float m0 = wave_sum(dot_frag(w0, h)), m1 = wave_sum(dot_frag(w1, h));
-      const float q0 = wave_sum(dot_frag(k0, h)), q1 = wave_sum(dot_frag(k1, h));
-      if (lane < 2) {
-        const size_t idx = ((size_t)s * a.E + e) * d + row0 + lane;
-        a.msg[idx] = (lane ? m1 : m0) * bias;
-        a.keyv[idx] = lane ? q1 : q0;
+    RowFrag<DCH> w0, w1, k0, k1;
+    float bias = 0.f;
+    bool loaded = false;
+    for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+      const int sl = sc + lane * nz;
+      unsigned long long act = __ballot(sl < a.S && prev_on(a, sl, src));
+      if (!act) continue;
+      if (!loaded) {  // (wave-uniform) idle workgroups never ask for their rows
+        const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
+        const float* K = a.key_W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
+        load_row(w0, W, d, lane);
+        load_row(w1, W + d, d, lane);
+        load_row(k0, K, d, lane);
+        load_row(k1, K + d, d, lane);
+        bias = a.ebias[e];
+        loaded = true;
+      }
+      while (act) {
+        int sv[2];
+        RowFrag<DCH> h[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          sv[u] = -1;
+          if (act) {
+            sv[u] = sc + (__ffsll((long long)act) - 1) * nz;
+            act &= act - 1;
+            load_row(h[u], h_row(a, sv[u], src), d, lane);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (sv[u] < 0) continue;  // wave-uniform
+          const float m0 = wave_sum(dot_frag(w0, h[u])), m1 = wave_sum(dot_frag(w1, h[u]));
+          const float q0 = wave_sum(dot_frag(k0, h[u])), q1 = wave_sum(dot_frag(k1, h[u]));
+          if (lane < 2) {
+            const size_t idx = ((size_t)sv[u] * a.E + e) * d + row0 + lane;
+            a.msg[idx] = (lane ? m1 : m0) * bias;
+            a.keyv[idx] = lane ? q1 : q0;
+          }
+        }
       }
     }
   } else {
     const int r = y - a.E;
     const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
     const float* Q = a.query_W + (size_t)r * dd + (size_t)row0 * d;
-    RowFrag<DCH> q0, q1, h;
+    RowFrag<DCH> q0, q1;
     bool loaded = false;
-    for (int s = blockIdx.z; s < a.S; s += gridDim.z) {
-      bool any = false;
-      for (int e = e0; e < e1; ++e) any |= prev_on(a, s, a.src[e]);
-      if (!any) continue;
+    for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
+      const int sl = sc + lane * nz;
+      bool on = false;  // this lane's stream: any incoming edge with an active sender
+      if (sl < a.S)
+        for (int e = e0; e < e1; ++e) on |= prev_on(a, sl, a.src[e]);
+      unsigned long long act = __ballot(on);
+      if (!act) continue;
       if (!loaded) {
         load_row(q0, Q, d, lane);
         load_row(q1, Q + d, d, lane);
         loaded = true;
       }
-      load_row(h, h_row(a, s, r), d, lane);
-      const float v0 = wave_sum(dot_frag(q0, h)), v1 = wave_sum(dot_frag(q1, h));
-      if (lane < 2) a.q[((size_t)s * a.R + r) * d + row0 + lane] = lane ? v1 : v0;
+      while (act) {
+        int sv[2];
+        RowFrag<DCH> h[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          sv[u] = -1;
+          if (act) {
+            sv[u] = sc + (__ffsll((long long)act) - 1) * nz;
+            act &= act - 1;
+            load_row(h[u], h_row(a, sv[u], r), d, lane);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (sv[u] < 0) continue;
+          const float v0 = wave_sum(dot_frag(q0, h[u])), v1 = wave_sum(dot_frag(q1, h[u]));
+          if (lane < 2) a.q[((size_t)sv[u] * a.R + r) * d + row0 + lane] = lane ? v1 : v0;
+        }
+      }
     }
   }
 }

@@ -75,7 +75,7 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
         for c in cells:
             c.to(dev)
         bank.to_device()
-        router = Router(nb, d, R).to(dev)
+        router = Router(nb, d, R, enable_precision_routed_messages=PRECISION).to(dev)
         nin = torch.ones(d, device=dev)
         for S in Ss:
             for k in ks:
@@ -122,7 +122,7 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
                 q_uniq = sum(int(torch.zeros(R, device=dev).index_add_(0, router.dst_idx, m.bool()[:, router.src_idx].any(0).float()).gt(0).sum())
                              for m in masks) / n_sets
                 pairs = sum(int(m.sum()) for m in masks) / n_sets
-                st = dict(u_f=uniq, n_f=pairs, u_b=uniq, n_b=pairs, e=e_uniq, ep=e_pairs, q=q_uniq, R=R, S=S, afd=False, prec=False,
+                st = dict(u_f=uniq, n_f=pairs, u_b=uniq, n_b=pairs, e=e_uniq, ep=e_pairs, q=q_uniq, R=R, S=S, afd=False, prec=PRECISION,
                           fsplit=(os.environ.get("IC_FWD_SPLIT") or ("1" if S >= 32 else "0"))[0] != "0")
                 row = {"R": R, "S": S, "k": k, "d": d, "rotate": len(masks), "backward": backward,
                        "unique_regions": uniq, "unique_edges": e_uniq, "pairs": pairs, "edge_pairs": e_pairs,
@@ -141,7 +141,8 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
         torch.cuda.empty_cache()
 
 
-SWEEP_KERNELS = ("region_pro", "region_rkv", "region_state", "region_out", "region_fin", "router_fwd", "region_out_bwd", "region_rkv_bwd",
+PRECISION = False  # --precision: precision-routed messages (key / query GEMVs + softmax combine)
+SWEEP_KERNELS = ("region_pro", "region_rkv", "region_state", "region_out", "region_fin", "router_fwd", "router_edge_fwd", "router_combine", "region_out_bwd", "region_rkv_bwd",
                  "region_mid_bwd", "region_pro_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_region", "wgrad_edge")
 
 
@@ -155,8 +156,11 @@ def main():
     ap.add_argument("--backward", action="store_true")
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many disjoint active sets")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event bracketing (run under rocprofv3)")
+    ap.add_argument("--precision", action="store_true")
     ap.add_argument("--flush-bwd", action="store_true", help="1 GiB read before every backward entry point (see flush_before_backward)")
     args = ap.parse_args()
+    global PRECISION
+    PRECISION = args.precision
     flush_before_backward(args.flush_bwd)
     for row in sweep(args.R, args.k, args.S, args.d, args.iters, args.backward, args.rotate, not args.no_events):
         print(json.dumps(row), flush=True)
