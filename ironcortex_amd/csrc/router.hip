@@ -915,9 +915,12 @@ static int check_router(const ic_router_args* a, const char* who) {
 
 // precision routing: an edge's workgroup walks its streams one after the other (sender mask byte, sender row, four
 // reductions each); with many streams they are split over gridDim.z, at most ~4-8 streams per workgroup
-static int edge_nz(int S) {
+// Streams over gridDim.z for the precision edge kernel: only while the (slice, edge) grid alone leaves the chip
+// short of workgroups.  Every z slice re-reads its edge's rows, and slices of one edge are dispatched far apart
+// (no L2 reuse): at R=512 (110k workgroups without z) a split by 8 multiplied the weight traffic.
+static int edge_nz(int S, int64_t base_wgs) {
   int nz = 1;
-  while (nz * 8 <= S && nz < 8) nz *= 2;
+  while (nz * 8 <= S && nz < 8 && base_wgs * nz < 4096) nz *= 2;
   return nz;
 }
 
@@ -928,7 +931,7 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
   const int nsl = ic_ceil_div(a->d, kRowsPerBlock);
   if (a->flags & IC_RF_PRECISION) {
     IC_DISPATCH_DCH(a->d, {
-      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R, edge_nz(a->S)), dim3(256), 0, st, *a));
+      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R, edge_nz(a->S, (int64_t)nsl * (a->E + a->R))), dim3(256), 0, st, *a));
     });
     const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
     if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
@@ -966,7 +969,7 @@ int ic_front_launch(const ic_gate_args* g, const ic_router_args* a, ic_stream_t 
   const int nsl = ic_ceil_div(a->d, kRowsPerBlock);
   if (a->flags & IC_RF_PRECISION) {
     IC_DISPATCH_DCH(a->d, {
-      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_front<DCH, true>), dim3(nsl, g->S + a->E + a->R, edge_nz(a->S)), dim3(256), 0, st, *a, *g));
+      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_front<DCH, true>), dim3(nsl, g->S + a->E + a->R, edge_nz(a->S, (int64_t)nsl * (a->E + a->R))), dim3(256), 0, st, *a, *g));
     });
     const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
     if (!combine) {
