@@ -48,6 +48,8 @@ def torch_attention(q, k, v, valid_len=None, alpha=None, lag_dt=1.0):
     (1, 4, 33, 32, 32, False, True),      # d=128 default width, AFA, one key past a tile
     (2, 4, 129, 8, 8, False, True),       # 8-wide heads alone, one query past a workgroup's block
     (1, 2, 200, 192, 128, False, False),  # d=512 widths
+    (16, 4, 520, 128, 64, True, False),   # the bench's batch (16 sequences x 4 heads), ragged
+    (16, 4, 520, 64, 64, False, True),
 ])
 def test_attention_forward_backward_vs_torch(B, H, T, dqk, dv, ragged, afa):
     from ironcortex_amd.hip import ops
