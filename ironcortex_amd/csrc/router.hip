@@ -1022,9 +1022,17 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
       IC_LAUNCH_CHECK("ic_router_bwd");
       return IC_OK;
     }
-    if (ny > 0 && many) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 8, 4>), dim3(nslab, ny, nz), blk, 0, st, *b));
+    // plain routing streams ONE matrix per edge: 64 rows per workgroup (as many bytes in flight as the precision
+    // path's 32 rows of two matrices) and half the slabs; the unused slabs of g_ebias_part stay zero
+    static const int rpw16_env = [] { const char* e = getenv("IC_MATT_RPW16"); return (e && e[0]) ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool rpw16 = many && !(a->flags & IC_RF_PRECISION) && nslab % 2 == 0 && nslab * ny >= 4096 && rpw16_env != 0;
+    int ns_used = nslab;
+    if (ny > 0 && rpw16) {
+      ns_used = nslab / 2;
+      IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 16, 4>), dim3(ns_used, ny, nz), blk, 0, st, *b));
+    } else if (ny > 0 && many) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_matT_bwd<DCH, 8, 4>), dim3(nslab, ny, nz), blk, 0, st, *b));
     else if (ny > 0) IC_TIMED(IC_KID_router_mat_bwd, st, hipLaunchKernelGGL((k_router_mat_bwd<DCH, 8>), dim3(nslab, ny, nz), blk, 0, st, *b));
-    IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, nslab));
+    IC_TIMED(IC_KID_router_gather_bwd, st, hipLaunchKernelGGL(k_router_gather_bwd<DCH>, grow, blk, 0, st, *b, ns_used));
   } else if (a->d <= 512) {
     constexpr int DCH = 2;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd_serial<DCH>, grow, blk, 0, st, *b, (int)dgrad_mfma));
