@@ -614,10 +614,17 @@ class AttnFn(torch.autograd.Function):
         return dq, dk, dvv, None, galpha, None, None
 
 
+def attention_fits(dqk: int, dv: int) -> bool:
+    """True when the library has an attention kernel for q/k rows of dqk and v rows of dv columns (after zero-padding)."""
+    return any(a >= dqk and b >= dv for a, b in ATTN_SHAPES)
+
+
 def attention(q, k, v, valid_len=None, alpha=None, lag_dt: float = 1.0, eps_log: float = 1e-9):
     """AttnFn with the rows zero-padded to a (dqk, dv) pair the library has kernels for (zero columns change neither
     the scores nor the kept output columns)."""
     dqk, dv = q.shape[-1], v.shape[-1]
+    if q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32:
+        raise RuntimeError("ic_attn: fp32 tensors only")
     fit = [(a, b) for a, b in ATTN_SHAPES if a >= dqk and b >= dv]
     if not fit:
         raise RuntimeError(f"ic_attn: no kernel for q/k rows of {dqk} and v rows of {dv} columns")

@@ -7,8 +7,9 @@ How the reference's arithmetic reaches that kernel without changing results:
   * the Fourier relative bias b(p_q - p_k) is a rank-2m feature product (cos/sin addition theorem), so it
     rides as 2m extra q / k columns instead of a [B,T,T,m] tensor; 1/sqrt(hd) is folded into q;
   * no [1,1,max_T,max_T] mask buffer for the bidirectional case; padded anchor rows are a per-sample key count.
-Options the mixer never uses (causal, an explicit context mask, attention dropout > 0, an AFA mask) keep the
-plain PyTorch formulation of the same arithmetic (`*_torch`), which is also the tests' fp32 reference."""
+Options the mixer never uses (causal, an explicit context mask, attention dropout > 0, an AFA mask) and heads
+wider than the kernels' 128 columns (d = 1024 with 4 heads) keep the plain PyTorch formulation of the same
+arithmetic (`*_torch`), which is also the tests' fp32 reference."""
 from __future__ import annotations
 
 import math
@@ -137,6 +138,7 @@ class IronRoPESelfAttention(nn.Module):
             c, s = torch.cos(theta).unsqueeze(1), torch.sin(theta).unsqueeze(1)
             q, k = rope_rotate_pairs(q, c, s, self.rope_m), rope_rotate_pairs(k, c, s, self.rope_m)
         plain = not self.causal and context_mask is None and not (dropout and self.training and self.adrop.p > 0)
+        plain = plain and ops.attention_fits(self.head_dim + 2 * self.fb_m, self.head_dim)  # heads wider than 128: [T,T] path
         if plain:  # the library's kernels
             y = self._attend_hip(q, k, v, coords, valid_len)
         else:
@@ -221,7 +223,7 @@ class AdaptiveFilterAttention(FastAttrs, nn.Module):
         self.last_attn_entropy = torch.tensor(0.0)
 
     def _attend(self, q, k, v, mask):
-        if mask is None:
+        if mask is None and ops.attention_fits(self.head_dim, self.head_dim):  # (heads wider than 128: [T,T] path)
             return self._attend_hip(q, k, v)
         return self._attend_torch(q, k, v, mask)
 

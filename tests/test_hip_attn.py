@@ -137,3 +137,17 @@ def test_afa_module_hip_equals_torch_formulation(d, T):
     close(res[0][4], res[1][4], "dx", tol=1e-4)
     for n in res[0][5]:
         close(res[0][5][n], res[1][5][n], "grad " + n, tol=1e-4)
+
+
+def test_heads_wider_than_the_kernels_keep_the_torch_formulation():
+    """d = 1024 with 4 heads (256-wide heads, beyond the kernels' 128 value columns): both attention modules still
+    run (the [T,T] formulation), forward and backward."""
+    from ironcortex_amd.hip import ops
+    from ironcortex_amd.mixer import AdaptiveFilterAttention, IronRoPESelfAttention
+    assert not ops.attention_fits(256, 256) and ops.attention_fits(72, 8) and ops.attention_fits(128, 128)
+    x = gi.det(9500, 2, 40, 1024).to(DEV).requires_grad_(True)
+    for att in (IronRoPESelfAttention(n_embd=1024, n_head=4, block_size=64).to(DEV), AdaptiveFilterAttention(1024, 4).to(DEV)):
+        y = att(x)
+        y.sum().backward()
+        assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+        assert torch.isfinite(att.last_attn_energy_b).all()
