@@ -473,6 +473,25 @@ int ic_prof_read(int kid, int64_t* launches, double* total_ms);
  * device-side unit counts (bench.py). */
 int ic_prof_bytes_read(int kid, int64_t* launches, double* bytes);
 
+/* ---------------------------------------------------------------- heads that carry a gradient
+ * Backward of y = act(W x + b) over B <= 16 rows: the planner / critic / RTD heads and the energy verifier's
+ * linear layers that train_step differentiates through (reference heads.py:39-91 MLP / PlannerHead / CriticHead /
+ * RTDHead, energy.py:12-30; their autograd in training.py:158-231).  The forward is ic_gemv_chain with
+ * nbatch = B; the pre-activation is recomputed here.  gW / gb are WRITTEN (not accumulated); every output row
+ * has one owner and the input gradient is summed in a fixed order: no float atomics. */
+typedef struct ic_linear_bwd_args {
+  int32_t B, n, rows, act; /* batch rows, input columns, output rows, IC_ACT_* */
+  const float* W;          /* [rows,n] */
+  const float* b;          /* [rows] or NULL */
+  const float* x;          /* [B,n] */
+  const float* gy;         /* [B,rows] */
+  float* gx;               /* [B,n] or NULL */
+  float* gW;               /* [rows,n] or NULL */
+  float* gb;               /* [rows] or NULL */
+  float* slab;             /* [ceil(rows/32),B,n] workspace, needed when gx != NULL and rows > 32 */
+} ic_linear_bwd_args;
+int ic_linear_bwd(const ic_linear_bwd_args* a, ic_stream_t stream);
+
 /* ---------------------------------------------------------------- token-mixer attention
  * Replaces the score / softmax / statistics / value product of reference iron_rope.py:201-235
  * (IronRoPESelfAttention.forward: q k^T / sqrt(hd) + relative Fourier bias, key padding, softmax, att @ v and the

@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .heads import VecLinear
+from .hip import ops
 
 
 class EnergyVerifierHead(nn.Module):
@@ -27,7 +28,13 @@ class EnergyVerifierHead(nn.Module):
             elif aux.dim() == 1:
                 aux = aux.unsqueeze(0).expand(ctx.shape[0], -1)
             parts.append(aux)
-        return self.net(torch.cat(parts, dim=-1)).squeeze(-1)
+        z = torch.cat(parts, dim=-1)
+        if ops.linear_act_fits(z):  # train_step's loss rows: LayerNorm in PyTorch, the three layers on the library
+            ln, l0, l1, l2 = self.net[0], self.net[1], self.net[3], self.net[5]
+            h = F.layer_norm(z, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+            h = ops.linear_act(ops.linear_act(h, l0.weight, l0.bias, "silu"), l1.weight, l1.bias, "silu")
+            return ops.linear_act(h, l2.weight, l2.bias).squeeze(-1)
+        return self.net(z).squeeze(-1)
 
 
 def energy_descent_step(verifier, ctx, y_hat, alpha: float, sigma: float = 0.0, clamp=None):

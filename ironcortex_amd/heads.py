@@ -1,11 +1,13 @@
-"""Workspace and the small heads around the inner step (reference heads.py:12-119).
-Plain PyTorch on the GPU except the workspace sparsifier, which is the HIP KWTA kernel."""
+"""Workspace and the small heads around the inner step (reference heads.py:12-119).  The workspace sparsifier
+is the HIP KWTA kernel; the MLP / RTD heads take the library's fused linear layers (forward ic_gemv_chain, backward
+ic_linear_bwd) on the small row batches train_step differentiates through, plain PyTorch otherwise."""
 from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .hip import ops
 from .utils import KWTA, FastAttrs, RMSNorm
 
 
@@ -44,6 +46,9 @@ class MLP(nn.Module):
         self.net = nn.Sequential(VecLinear(d_in, hidden), nn.GELU(), VecLinear(hidden, d_out))
 
     def forward(self, x):
+        if ops.linear_act_fits(x):  # train_step's loss rows: fused layers with the library's backward
+            l0, l1 = self.net[0], self.net[2]
+            return ops.linear_act(ops.linear_act(x, l0.weight, l0.bias, "gelu"), l1.weight, l1.bias)
         return self.net(x)
 
 
@@ -88,6 +93,8 @@ class RTDHead(nn.Module):
         self.clf = VecLinear(d, 2)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if ops.linear_act_fits(x):
+            return ops.linear_act(x, self.clf.weight, self.clf.bias)
         return self.clf(x)
 
 

@@ -567,6 +567,51 @@ class GoodnessFn(torch.autograd.Function):
         return gH.view(ctx.shape)
 
 
+LINEAR_MAX_ROWS = 16  # batch rows ic_linear_bwd takes
+ACTS = {"none": ENUMS["IC_ACT_NONE"], "gelu": ENUMS["IC_ACT_GELU"], "silu": ENUMS["IC_ACT_SILU"]}
+
+
+class LinearActFn(torch.autograd.Function):
+    """y = act(x W^T + b) for x [B <= 16, n] (heads.py:39-91, energy.py:12-30 on train_step's loss rows): forward
+    ic_gemv_chain (one launch), backward ic_linear_bwd (pre-activation recomputed; gW / gb / gx without atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act: int):
+        B, n = x.shape
+        rows = W.shape[0]
+        x, W = x.contiguous(), W.contiguous()
+        y = torch.empty(B, rows, device=x.device)
+        g = new("ic_gemv_desc", W=W, b=b, x0=x, y=y, n0=n, rows=rows, act=act, nbatch=B, x0_bs=n, y_bs=rows)
+        check(lib().ic_gemv_chain(ctypes.byref(g), ctypes.c_int32(1), stream_handle()), "ic_gemv_chain")
+        ctx.save_for_backward(x, W, b)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, b = ctx.saved_tensors
+        B, n = x.shape
+        rows = W.shape[0]
+        need_x, need_W, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], b is not None and ctx.needs_input_grad[2]
+        gx = torch.empty_like(x) if need_x else None
+        gW = torch.empty_like(W) if need_W else None
+        gb = torch.empty_like(b) if need_b else None
+        nblk = (rows + 31) // 32
+        slab = torch.empty(nblk, B, n, device=x.device) if need_x and nblk > 1 else None
+        a = new("ic_linear_bwd_args", B=B, n=n, rows=rows, act=ctx.act, W=W, b=b, x=x, gy=gy.contiguous(), gx=gx, gW=gW, gb=gb, slab=slab)
+        _call("ic_linear_bwd", a)
+        return gx, gW, gb, None
+
+
+def linear_act(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act: str = "none") -> torch.Tensor:
+    return LinearActFn.apply(x, W, b, ACTS[act])
+
+
+def linear_act_fits(x: torch.Tensor) -> bool:
+    """A small fp32 batch of rows on the device: the shape of every loss head of train_step."""
+    return x.is_cuda and x.dim() == 2 and 1 <= x.shape[0] <= LINEAR_MAX_ROWS and x.dtype == torch.float32
+
+
 ATTN_SHAPES = ((32, 32), (64, 64), (128, 128), (96, 32), (128, 64), (192, 128))  # (dqk, dv) the library has kernels for
 
 

@@ -151,3 +151,34 @@ def test_heads_wider_than_the_kernels_keep_the_torch_formulation():
         y.sum().backward()
         assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
         assert torch.isfinite(att.last_attn_energy_b).all()
+
+
+# ---------------------------------------------------------------- fused linear layers of the loss heads (ic_linear_bwd)
+@pytest.mark.parametrize("B,n,rows,act", [(8, 256, 256, "gelu"), (16, 515, 256, "silu"), (8, 512, 1, "none"),
+                                           (3, 256, 2, "none"), (1, 40, 33, "gelu"), (16, 512, 512, "gelu")])
+def test_linear_act_forward_backward_vs_torch(B, n, rows, act):
+    """y = act(x W^T + b) on the library (forward ic_gemv_chain, backward ic_linear_bwd) against F.linear + the
+    activation under torch autograd: outputs and all three gradients, 1e-5 of the largest magnitude; twice the same bits."""
+    import torch.nn.functional as F
+    from ironcortex_amd.hip import ops
+    seed = 9600 + n + rows
+    x = gi.det(seed, B, n).to(DEV).requires_grad_(True)
+    W = gi.det(seed + 1, rows, n, kind="xavier").to(DEV).requires_grad_(True)
+    b = gi.det(seed + 2, rows, scale=0.1).to(DEV).requires_grad_(True)
+    probe = gi.det(seed + 3, B, rows).to(DEV)
+    fn = {"gelu": F.gelu, "silu": F.silu, "none": lambda t: t}[act]
+    y = ops.linear_act(x, W, b, act)
+    (y * probe).sum().backward()
+    got = [t.grad.clone() for t in (x, W, b)]
+    for t in (x, W, b):
+        t.grad = None
+    yw = fn(F.linear(x, W, b))
+    (yw * probe).sum().backward()
+    close(y, yw, "y", tol=1e-5)
+    for g, t, nm in zip(got, (x, W, b), ("gx", "gW", "gb")):
+        close(g, t.grad, nm, tol=1e-5)
+    for t in (x, W, b):
+        t.grad = None
+    y2 = ops.linear_act(x, W, b, act)
+    (y2 * probe).sum().backward()
+    assert torch.equal(y2, y) and all(torch.equal(g, t.grad) for g, t in zip(got, (x, W, b)))
