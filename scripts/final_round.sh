@@ -6,6 +6,7 @@ OUT=$R/gpurun_out
 cd $R
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > $OUT/gpu_tests.log 2>&1 || { tail -20 $OUT/gpu_tests.log; exit 1; }
 tail -2 $OUT/gpu_tests.log
+timeout -k 10 200 python -u -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 || exit 1
 timeout -k 10 500 python -u bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err || { tail -5 $OUT/bench_final.err; exit 1; }
 tail -c 600 $OUT/bench_final.json; echo
 timeout -k 10 400 python -u bench.py --config default --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err || { tail -5 $OUT/bench_default.err; exit 1; }
