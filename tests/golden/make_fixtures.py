@@ -273,14 +273,26 @@ MODEL_CASES = {
                      enable_radial_tangential_updates=True, enable_afa_attention=True,
                      enable_ff_energy_alignment=True, surprise_lambda=0.05, tau_kappa=0.01),
 }
+# corners of the configuration space (same fixture layout; `corner` on the command line)
+CORNER_CASES = {
+    "kactive2": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=2, max_T=64),  # k_total = 0 (utils.py:118-120)
+    "softkwta": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, kwta_soft_mode=True, kwta_k_start=12,
+                     kwta_k_schedule=10, kwta_soft_temp=0.5),
+    "nopred_nokwta": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, use_predictive_trace=False,
+                          disable_kwta_during_gating=True),
+}
 MODEL_B, MODEL_T = 2, 24
 
 
-def model_fixture():
+def corner_fixture():
+    model_fixture(CORNER_CASES)
+
+
+def model_fixture(cases=None):
     import copy
     import random
     from ironcortex import CortexConfig, CortexReasoner, LossWeights, train_step
-    for name, kw in MODEL_CASES.items():
+    for name, kw in (cases or MODEL_CASES).items():
         torch.manual_seed(11); random.seed(11)
         cfg = CortexConfig(**kw)
         model = CortexReasoner(hex_neighbors(cfg.R), hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)

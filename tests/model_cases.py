@@ -16,6 +16,14 @@ MODEL_CASES = {
                      enable_radial_tangential_updates=True, enable_afa_attention=True,
                      enable_ff_energy_alignment=True, surprise_lambda=0.05, tau_kappa=0.01),
 }
+# corners of the configuration space, same fixture layout (tests/golden/make_fixtures.py `corner`)
+CORNER_CASES = {
+    "kactive2": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=2, max_T=64),  # k_total = 0 (utils.py:118-120)
+    "softkwta": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, kwta_soft_mode=True, kwta_k_start=12,
+                     kwta_k_schedule=10, kwta_soft_temp=0.5),
+    "nopred_nokwta": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, use_predictive_trace=False,
+                          disable_kwta_during_gating=True),
+}
 MODEL_B, MODEL_T = 2, 24
 
 # Full-size cases: the exact bench model (reference train_tiny_shakespeare_10m.py:32-48)
@@ -58,7 +66,7 @@ def load_case(name):
                 sd[k] = gi.synth_tensor(int(spec[0]), [int(x) for x in spec[3:]], float(spec[1]), float(spec[2]))
         tokens, focus = big_inputs(name)
         return gold, cfg, sd, tokens, focus
-    cfg = CortexConfig(**MODEL_CASES[name])
+    cfg = CortexConfig(**(MODEL_CASES[name] if name in MODEL_CASES else CORNER_CASES[name]))
     sd = {k[3:]: torch.as_tensor(gold[k]) for k in gold.files if k.startswith("sd.")}
     tokens = (gi.det(31, MODEL_B, MODEL_T, kind="rand") * (cfg.V - 1)).long()
     focus = gi.det(32, MODEL_B, MODEL_T, kind="rand") < 0.3

@@ -14,7 +14,7 @@ import torch
 
 from tests import parity_log as PL
 from tests.golden import inputs as gi
-from tests.model_cases import BIG_CASES, MODEL_CASES, grad_probes, load_case, seed_train
+from tests.model_cases import BIG_CASES, CORNER_CASES, MODEL_CASES, grad_probes, load_case, seed_train
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -30,7 +30,7 @@ def build(cfg, sd):
     return model.to(DEV)
 
 
-ALL_CASES = list(MODEL_CASES) + list(BIG_CASES)
+ALL_CASES = list(MODEL_CASES) + list(CORNER_CASES) + list(BIG_CASES)
 # Tolerances (relative to the reference tensor's largest magnitude; see tests/parity_log.py).
 # TOL_* are ~3x the worst error OBSERVED on MI355X over all cases (profiles/r02_parity_errors.jsonl);
 # the north_star asks for "about 1e-5 relative" and every forward quantity meets it.
@@ -393,7 +393,11 @@ def test_train_trajectory_equals_oracle_over_six_steps():
     (dict(R=7, d=32, V=32, K_inner=2, B_br=1, k_active=4, max_T=64), 2),     # two-token sequences, one branch
     (dict(R=10, d=64, V=32, K_inner=3, B_br=2, k_active=5, max_T=64, enable_afa_attention=True,
           enable_precision_routed_messages=True), 17),                      # odd length, 16-wide attention heads, precision routing
-], ids=["k_active2", "R4", "T2_onebranch", "d64_afa_precision"])
+    (dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, kwta_soft_mode=True, kwta_k_start=12,
+          kwta_k_schedule=10, kwta_soft_temp=0.5), 24),                      # soft KWTA warm-up with a winner-count schedule (region.py:238-248)
+    (dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, use_predictive_trace=False), 24),
+    (dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, disable_kwta_during_gating=True), 24),
+], ids=["k_active2", "R4", "T2_onebranch", "d64_afa_precision", "kwta_soft_schedule", "no_pred_trace", "no_kwta"])
 def test_corner_configs_two_train_steps_equal_oracle(kw, T):
     """Corners the fixtures do not hold, checked the way test_train_trajectory_* is: two train_steps of the product
     against the oracle model from the same weights, tokens and random streams (metrics to 1e-4)."""
