@@ -280,6 +280,11 @@ CORNER_CASES = {
                      kwta_k_schedule=10, kwta_soft_temp=0.5),
     "nopred_nokwta": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, use_predictive_trace=False,
                           disable_kwta_during_gating=True),
+    "afdvec": dict(R=10, d=32, V=32, K_inner=3, B_br=2, k_active=5, max_T=64, enable_adaptive_filter_dynamics=True,
+                   afd_noise_mode="vector", enable_radial_tangential_updates=True, kwta_k=6, router_vectorized=False),
+    "noff_surprise": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, enable_forward_forward=False,
+                          enable_adaptive_filter_dynamics=True, enable_ff_energy_alignment=True, surprise_lambda=0.1,
+                          surprise_lambda_schedule=4, init_decay=0.5),
 }
 MODEL_B, MODEL_T = 2, 24
 
