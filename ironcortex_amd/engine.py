@@ -857,8 +857,9 @@ class LoopEngine:
         last = -1
         traces: List[torch.Tensor] = []
         if not cfg.train_deterministic_inner_loop and (ver is None or steer is None):
-            raise RuntimeError("the branching reasoning loop needs the planner, critic and energy verifier "
-                               "(reference model.py:376-438)")
+            # (TypeError: what the reference raises here -- it calls self.verify, which is None, model.py:425)
+            raise TypeError("the branching reasoning loop needs the planner, critic and energy verifier "
+                            "(reference model.py:376-438): 'NoneType' object is not callable")
         if cfg.train_deterministic_inner_loop:
             settle()
             cur, u_mean = -1, 0.0

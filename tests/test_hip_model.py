@@ -446,3 +446,18 @@ def test_three_branches_raise_as_in_the_reference():
         model.engine.enabled = engine
         with pytest.raises(IndexError), torch.no_grad():
             model.reasoning_loop_batch(tokens, cfg.K_inner, torch.zeros_like(tokens, dtype=torch.bool))
+
+
+def test_branching_loop_without_verifier_raises_as_in_the_reference():
+    """enable_energy_verifier=False leaves model.verify None and the reference's branching loop calls it
+    (model.py:425): TypeError.  Both host paths raise the same type."""
+    import ironcortex_amd as ic
+    from ironcortex_amd.config import CortexConfig
+    cfg = CortexConfig(R=7, d=32, V=32, K_inner=2, B_br=2, k_active=4, max_T=64, enable_energy_verifier=False)
+    torch.manual_seed(13)
+    model = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg).to(DEV)
+    tokens = (gi.det(65, 1, 16, kind="rand") * (cfg.V - 1)).long().to(DEV)
+    for engine in (True, False):
+        model.engine.enabled = engine
+        with pytest.raises(TypeError), torch.no_grad():
+            model.reasoning_loop_batch(tokens, cfg.K_inner, torch.zeros_like(tokens, dtype=torch.bool))
