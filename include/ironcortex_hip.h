@@ -120,6 +120,10 @@ typedef struct ic_region_args {
   float* gate;  /* [S,R,d] KWTA multiplier (0/1 hard) */
   float* ynorm; /* [S,R]  RT only */
   float* sterm; /* [S,R,d] AFD surprise terms */
+  const int32_t* dead; /* NULL, or one device word read at run time: non-zero turns the launch into a pass-through
+                          (every region inactive, state / trace / dt copied unchanged, H = 0) -- an outer iteration
+                          queued behind a reasoning loop that has already halted (device-steered loops, ic_loop_steer:
+                          the host launches every iteration without knowing whether should_halt has fired) */
 } ic_region_args;
 
 int ic_region_phase_fwd(const ic_region_args* a, ic_stream_t stream);
@@ -291,8 +295,10 @@ typedef struct ic_gate_args {
   const int32_t* in_slot;   /* [S] stream s reads H block in_slot[s] (R*d floats per block; H_sstride ignored) */
   const float* t5_s;        /* [S] replaces t5 (each loop has its own critic value) */
   const float* t6_s;        /* [S] replaces t6 (its own uncertainty) */
-  const int32_t* k_total_s; /* [S] replaces k_total (its own burst) */
+  const int32_t* k_total_s; /* [S] replaces k_total (its own burst); IC_GATE_OFF: the stream selects NOTHING (empty
+                               mask, the forced pair included): an iteration behind a loop that has halted */
 } ic_gate_args;
+enum { IC_GATE_OFF = -(1 << 30) };
 int ic_gate_scores(const ic_gate_args* a, ic_stream_t stream);
 /* Gate.select_k + nms_topk (gate.py:70-87, utils.py:107-124).  Total order: score
  * descending, index ascending (stable); quirks of the greedy walk are reproduced. */
@@ -451,6 +457,64 @@ typedef struct ic_steer_args {
   float* motor;                 /* [d] */
 } ic_steer_args;
 int ic_steer_select(const ic_steer_args* a, ic_stream_t stream);
+
+/* ------------------------------------------------------------------ device-side steering of the branching loop
+ * The control flow of reference model.py:371-452 between two outer iterations, decided ON THE DEVICE so that the
+ * host can queue every launch of every loop of a batch without waiting for a result (and capture them in a HIP
+ * graph): rank the C <= 2 branches of the iteration that just ran by their scores (descending, first on ties:
+ * the order the host code takes), hand the winner's states to the next iteration as parents, take ITS critic
+ * value v_hat and the uncertainty u of the iteration's last logits (utils.py:127-130), derive the burst
+ * (utils.py:140-144), the gate's two scalar terms (gate.py:58-67: t5 = fp32(w5 * v_hat), t6 = fp32(w6 * u),
+ * products formed in double as the host does) and the halting test (utils.py:147-151).  The launches of the next
+ * iteration read all of that from a CONTROL BLOCK through the per-stream indirections that exist for multi-stream
+ * launches (ic_gate_args.in_slot / k_total_s / t5_s / t6_s, ic_router_args.in_slot, ic_heads_args.par_slot /
+ * slots_slot, ic_region_args.dead).  The kernel also runs the critic's scalar output layer (heads.py:69-70) for
+ * the C candidates -- same arithmetic as ic_gemv_chain -- so it REPLACES that launch instead of adding one.
+ *
+ * Control block = IC_CTL_WORDS 32-bit words:
+ *   [IC_CTL_IN_SLOT + c]    arena slot whose H / mask branch c starts from       (int32)
+ *   [IC_CTL_SLOTS_SLOT + c] arena slot whose workspace it starts from            (int32)
+ *   [IC_CTL_K_TOTAL + c]    k_active + burst, or IC_GATE_OFF when the loop has halted (int32)
+ *   [IC_CTL_T5 + c], [IC_CTL_T6 + c]  the gate's scalar terms                    (float)
+ *   [IC_CTL_DEAD]           1: the loop halted before this iteration (its launches are pass-throughs)
+ *   [IC_CTL_HALT]           1: this iteration is the loop's last (should_halt fires after it)
+ *   [IC_CTL_TOP]            winning branch of the PREVIOUS iteration (-1: none), for the host's record
+ *   [IC_CTL_U], [IC_CTL_VHAT]  u_mean and v_hat the iteration runs with (float), for the host's record
+ */
+enum {
+  IC_CTL_WORDS = 32,
+  IC_CTL_IN_SLOT = 0, IC_CTL_SLOTS_SLOT = 4, IC_CTL_K_TOTAL = 8, IC_CTL_T5 = 12, IC_CTL_T6 = 16,
+  IC_CTL_DEAD = 20, IC_CTL_HALT = 21, IC_CTL_TOP = 22, IC_CTL_U = 23, IC_CTL_VHAT = 24
+};
+enum {
+  IC_STEER_INIT = 0, /* write the first block of the first loop of a batch (no iteration has run) */
+  IC_STEER_STEP = 1, /* after iteration k < K_inner - 1: ctl_next is the block of iteration k + 1 */
+  IC_STEER_LAST = 2  /* after iteration K_inner - 1: ctl_next is the first block of the NEXT loop (or NULL) */
+};
+typedef struct ic_loop_steer_args {
+  int32_t mode;          /* IC_STEER_* */
+  int32_t C;             /* branches per outer iteration, 1 or 2 */
+  int32_t R, k_active;   /* burst = max(1, R / 8); k_total = max(0, k_active + burst) */
+  int32_t k, K_inner;    /* index of the iteration that just ran; iterations per loop */
+  int32_t slot0;         /* arena slot of its branch 0 (branch c: slot0 + c) */
+  int32_t zero_slot;     /* slot of the all-zero input state (H = 0, mask = 0) every loop starts from; the first
+                            loop of a batch also takes its workspace from it (IC_STEER_INIT) */
+  double w5, w6;         /* Gate.w5, Gate.w6 */
+  const float* crit_W;   /* [crit_cols] the critic's output layer (rows = 1); NULL: no critic value (v_hat = 0) */
+  const float* crit_b;   /* [1] or NULL */
+  const float* crit_x;   /* [C, crit_cols] its input for every candidate */
+  int32_t crit_cols;     /* <= 1024 */
+  int32_t pad_;
+  float* vhat;           /* [C] out: the candidates' critic values */
+  const float* scores;   /* [C] branch scores of iteration k (model.py:431-438) */
+  const float* stats;    /* [C,4] ic_heads_args.stats of its branches */
+  const float* vhat0;    /* [1] critic value of the all-zero state (first iteration of every loop) */
+  const int32_t* ctl;    /* control block iteration k ran with (unused by IC_STEER_INIT) */
+  int32_t* ctl_next;     /* block to fill, see mode; NULL: nothing follows */
+  int32_t* rec;          /* [4] record of the loop, kept up to date while it is live: slot of the winner so far,
+                            last executed slot, executed steps, executed iterations */
+} ic_loop_steer_args;
+int ic_loop_steer(const ic_loop_steer_args* a, ic_stream_t stream);
 
 /* ------------------------------------------------------------------ measurement hooks
  * No counterpart in the reference (its cfg.profile timers read perf_counter without a device

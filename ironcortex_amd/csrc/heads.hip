@@ -737,6 +737,112 @@ __global__ __launch_bounds__(256) void k_steer_select(ic_steer_args a) {
   }
 }
 
+// ---------------------------------------------------------------- device-side steering (ic_loop_steer)
+// One workgroup.  Wave c < C runs the critic's scalar output layer for candidate c with the arithmetic of
+// gemv_reg_body (lane-strided columns, one fmaf chain per lane, wave_sum), then thread 0 takes the decisions of
+// reference model.py:371-392,440-452 for the next outer iteration and writes its control block.
+__device__ __forceinline__ void ctl_zero_state(const ic_loop_steer_args& a, int32_t* nx, int ws_slot) {
+  const float v = a.vhat0 ? a.vhat0[0] : 0.f;
+  const int burst = ((double)v > 0.0) ? (a.R / 8 > 1 ? a.R / 8 : 1) : 0;  // utils.py:140-144 with u_mean = 0
+  const int kt = a.k_active + burst > 0 ? a.k_active + burst : 0;
+  const float t5 = (float)(a.w5 * (double)v), t6 = (float)(a.w6 * 0.0);
+  for (int c = 0; c < 4; ++c) {
+    nx[IC_CTL_IN_SLOT + c] = a.zero_slot;
+    nx[IC_CTL_SLOTS_SLOT + c] = ws_slot;
+    nx[IC_CTL_K_TOTAL + c] = kt;
+    nx[IC_CTL_T5 + c] = __float_as_int(t5);
+    nx[IC_CTL_T6 + c] = __float_as_int(t6);
+  }
+  nx[IC_CTL_DEAD] = 0;
+  nx[IC_CTL_HALT] = 0;  // utils.py:147-151: k = 0 < max(1, K_inner / 2)
+  nx[IC_CTL_TOP] = -1;
+  nx[IC_CTL_U] = __float_as_int(0.f);
+  nx[IC_CTL_VHAT] = __float_as_int(v);
+}
+
+__global__ __launch_bounds__(256) void k_loop_steer(ic_loop_steer_args a) {
+  __shared__ float vh[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = a.C;
+  if (a.mode != IC_STEER_INIT && wave < C) {
+    float out = 0.f;
+    if (a.crit_W) {
+      constexpr int NX = 16;  // crit_cols <= 1024 (checked on the host); same lane / column mapping as k_gemv_reg
+      const float* x = a.crit_x + (size_t)wave * a.crit_cols;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int c = lane + 64 * i;
+        const float xv = c < a.crit_cols ? x[c] : 0.f;
+        const float wv = c < a.crit_cols ? a.crit_W[c] : 0.f;
+        acc = fmaf(wv, xv, acc);
+      }
+      acc = wave_sum(acc);
+      out = acc + (a.crit_b ? a.crit_b[0] : 0.f);
+    }
+    if (lane == 0) {
+      vh[wave] = out;
+      if (a.vhat) a.vhat[wave] = out;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  int32_t* nx = a.ctl_next;
+  if (a.mode == IC_STEER_INIT) {
+    if (nx) ctl_zero_state(a, nx, a.zero_slot);
+    return;
+  }
+  const int32_t* cur = a.ctl;
+  const bool dead = cur[IC_CTL_DEAD] != 0;
+  int top0 = 0;
+  if (!dead) {
+    top0 = (C == 2 && a.scores[1] > a.scores[0]) ? 1 : 0;  // score descending, first on ties
+    a.rec[0] = a.slot0 + top0;
+    a.rec[1] = a.slot0 + C - 1;
+    a.rec[2] = (a.k + 1) * C;
+    a.rec[3] = a.k + 1;
+  }
+  if (!nx) return;
+  if (a.mode == IC_STEER_LAST) {  // the next loop starts from the zero state and the winner's workspace
+    ctl_zero_state(a, nx, a.rec[0]);
+    return;
+  }
+  if (dead || cur[IC_CTL_HALT] != 0) {  // the loop is over: what is queued behind it passes the state through
+    for (int c = 0; c < 4; ++c) {
+      nx[IC_CTL_IN_SLOT + c] = cur[IC_CTL_IN_SLOT + c];
+      nx[IC_CTL_SLOTS_SLOT + c] = cur[IC_CTL_SLOTS_SLOT + c];
+      nx[IC_CTL_K_TOTAL + c] = IC_GATE_OFF;
+      nx[IC_CTL_T5 + c] = 0;
+      nx[IC_CTL_T6 + c] = 0;
+    }
+    nx[IC_CTL_DEAD] = 1;
+    nx[IC_CTL_HALT] = 0;
+    nx[IC_CTL_TOP] = dead ? -1 : top0;
+    nx[IC_CTL_U] = cur[IC_CTL_U];
+    nx[IC_CTL_VHAT] = cur[IC_CTL_VHAT];
+    return;
+  }
+  const float u = a.stats[(C - 1) * 4];  // uncertainty of the iteration's LAST logits (model.py:378,398)
+  const float v = vh[top0];              // the winner's critic value (model.py:384-386)
+  const int burst = ((double)u > 0.30 || (double)v > 0.0) ? (a.R / 8 > 1 ? a.R / 8 : 1) : 0;  // utils.py:140-144
+  const int kt = a.k_active + burst > 0 ? a.k_active + burst : 0;
+  const float t5 = (float)(a.w5 * (double)v), t6 = (float)(a.w6 * (double)u);
+  const int half = a.K_inner / 2 > 1 ? a.K_inner / 2 : 1;
+  for (int c = 0; c < 4; ++c) {
+    const int src = a.slot0 + (c == 0 ? top0 : (C == 2 ? 1 - top0 : top0));
+    nx[IC_CTL_IN_SLOT + c] = src;
+    nx[IC_CTL_SLOTS_SLOT + c] = src;
+    nx[IC_CTL_K_TOTAL + c] = kt;
+    nx[IC_CTL_T5 + c] = __float_as_int(t5);
+    nx[IC_CTL_T6 + c] = __float_as_int(t6);
+  }
+  nx[IC_CTL_DEAD] = 0;
+  nx[IC_CTL_HALT] = ((double)u < 0.05 && a.k + 1 >= half) ? 1 : 0;  // utils.py:147-151 for iteration k + 1
+  nx[IC_CTL_TOP] = top0;
+  nx[IC_CTL_U] = __float_as_int(u);
+  nx[IC_CTL_VHAT] = __float_as_int(v);
+}
+
 }  // namespace
 
 // weights once (the batches of a launch share them), input and output vectors per batch
@@ -994,5 +1100,28 @@ extern "C" int ic_steer_select(const ic_steer_args* a, ic_stream_t stream) {
   IC_BYTES(IC_KID_steer_select, 4.0 * (a->R + 2.0) * a->d + a->R);
   IC_TIMED(IC_KID_steer_select, st, hipLaunchKernelGGL(k_steer_select, dim3(1), dim3(256), 0, st, *a));
   IC_LAUNCH_CHECK("ic_steer_select");
+  return IC_OK;
+}
+
+extern "C" int ic_loop_steer(const ic_loop_steer_args* a, ic_stream_t stream) {
+  IC_REQUIRE(a != nullptr, "ic_loop_steer: NULL args");
+  IC_REQUIRE(a->mode >= IC_STEER_INIT && a->mode <= IC_STEER_LAST, "ic_loop_steer: mode=%d", a->mode);
+  IC_REQUIRE(a->C >= 1 && a->C <= 2, "ic_loop_steer: C=%d branches (need 1 or 2)", a->C);
+  IC_REQUIRE(a->R > 0 && a->K_inner > 0 && a->k >= 0 && a->k < a->K_inner, "ic_loop_steer: R=%d K_inner=%d k=%d", a->R,
+             a->K_inner, a->k);
+  IC_REQUIRE(a->zero_slot >= 0 && a->slot0 >= 0, "ic_loop_steer: negative slot");
+  if (a->mode == IC_STEER_INIT) {
+    IC_REQUIRE(a->ctl_next, "ic_loop_steer: IC_STEER_INIT needs ctl_next");
+  } else {
+    IC_REQUIRE(a->ctl && a->rec && a->scores && a->stats, "ic_loop_steer: NULL ctl / rec / scores / stats");
+    IC_REQUIRE((a->mode == IC_STEER_LAST) == (a->k == a->K_inner - 1), "ic_loop_steer: mode=%d at k=%d of %d", a->mode, a->k,
+               a->K_inner);
+    IC_REQUIRE(!a->crit_W || (a->crit_x && a->crit_cols > 0 && a->crit_cols <= 1024),
+               "ic_loop_steer: critic layer with %d columns (need 1..1024) or NULL input", a->crit_cols);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  IC_BYTES(IC_KID_loop_steer, a->crit_W ? 4.0 * (a->crit_cols * (1.0 + a->C) + 1) + 4.0 * IC_CTL_WORDS * 2 : 4.0 * IC_CTL_WORDS * 2);
+  IC_TIMED(IC_KID_loop_steer, st, hipLaunchKernelGGL(k_loop_steer, dim3(1), dim3(256), 0, st, *a));
+  IC_LAUNCH_CHECK("ic_loop_steer");
   return IC_OK;
 }

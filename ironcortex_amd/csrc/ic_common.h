@@ -218,9 +218,10 @@ enum IcKid {
   IC_KID_attn_bwd_kv,
   IC_KID_attn_bwd_q,
   IC_KID_linear_bwd,
+  IC_KID_loop_steer,
   IC_KID_COUNT
 };
-#define IC_KID_NAMES {"region_pro", "region_rkv", "region_out", "region_fin", "kwta_rows", "region_fin_bwd", "region_out_bwd", "region_mid_bwd", "region_rkv_bwd", "region_pro_bwd", "wgrad_region", "router_edge_fwd", "router_combine", "router_fwd", "router_comb_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_edge", "hebbian", "gate_scores", "gate_select", "mul", "rmsnorm_fwd", "rmsnorm_bwd", "goodness_fwd", "goodness_bwd", "gemv", "ws_write", "token_rows", "logits_combine", "branch_score", "steer_select", "router_mfma", "wgrad_mfma", "region_state", "attn_fwd", "attn_bwd_kv", "attn_bwd_q", "linear_bwd"}
+#define IC_KID_NAMES {"region_pro", "region_rkv", "region_out", "region_fin", "kwta_rows", "region_fin_bwd", "region_out_bwd", "region_mid_bwd", "region_rkv_bwd", "region_pro_bwd", "wgrad_region", "router_edge_fwd", "router_combine", "router_fwd", "router_comb_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_edge", "hebbian", "gate_scores", "gate_select", "mul", "rmsnorm_fwd", "rmsnorm_bwd", "goodness_fwd", "goodness_bwd", "gemv", "ws_write", "token_rows", "logits_combine", "branch_score", "steer_select", "router_mfma", "wgrad_mfma", "region_state", "attn_fwd", "attn_bwd_kv", "attn_bwd_q", "linear_bwd", "loop_steer"}
 
 // Optional live kernel timing with HIP events on the launch stream (ic_prof_* in the header).
 extern bool g_ic_prof_on;

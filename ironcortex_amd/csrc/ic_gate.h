@@ -36,6 +36,7 @@ __device__ __forceinline__ void gate_select_body(const ic_gate_args& a, int s, c
   if (threadIdx.x == 0) {
     uint8_t* mask = a.mask + s * R;
     const int kt = a.k_total_s ? a.k_total_s[s] : a.k_total;
+    if (kt == IC_GATE_OFF) return;  // a loop that has halted (ic_loop_steer): nothing is selected, the mask stays empty
     int k = kt > 0 ? kt : 0;
     if (a.force_io) {  // gate.py:80-84
       mask[a.sensor_idx] = 1;

@@ -683,7 +683,8 @@ __global__ __launch_bounds__(256) void k_region_fin(ic_region_args a, float one_
   const bool afd = a.flags & IC_F_AFD, rt = a.flags & IC_F_RT, pred = a.flags & IC_F_PRED;
   RowFrag<DCH> z;
   zero_frag(z);
-  if (a.mask[row]) {
+  const bool dead = a.dead && *a.dead != 0;  // pass-through launch (ic_region_args.dead)
+  if (!dead && a.mask[row]) {
     RowFrag<DCH> h, out, g;
     load_row(h, a.hpre + off, d, lane);
     if (a.flags & IC_F_NOKWTA) {
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(256) void k_region_fin(ic_region_args a, float one_
         t.v[j].z = al * p.v[j].z + one_minus_alpha * m.v[j].z;
         t.v[j].w = al * p.v[j].w + one_minus_alpha * m.v[j].w;
       }
-      store_row(t, a.pred_o + off, d, lane);
+      store_row(dead ? p : t, a.pred_o + off, d, lane);
     }
     load_row(t, a.num + off, d, lane);
     store_row(t, a.num_o + off, d, lane);
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(256) void k_region_fin(ic_region_args a, float one_
       store_row(t, a.var_o + off, d, lane);
     }
     if (lane == 0) {
-      a.dt_o[row] = a.dt[row] + 1;  // region.py:137-138
+      a.dt_o[row] = a.dt[row] + (dead ? 0 : 1);  // region.py:137-138
       if (afd) a.surprise_o[row] = a.surprise[row];
       if (rt) {
         a.radius_o[row] = a.radius[row];
@@ -770,10 +771,11 @@ __global__ __launch_bounds__(256) void k_region_fin_chain(ic_region_args a, floa
     RowFrag<DCH> h, st, m;
     bool on;
   };
+  const bool dead = a.dead && *a.dead != 0;  // pass-through launch (ic_region_args.dead): nothing active, nothing moves
   auto fetch = [&](int s, Pre& p) {
     const int row = s * a.R + r;
     const size_t off = (size_t)row * d;
-    p.on = a.mask[row] != 0;
+    p.on = !dead && a.mask[row] != 0;
     if (p.on) {
       load_row(p.h, a.hpre + off, d, lane);
       if (afd) load_row(p.st, a.sterm + off, d, lane);
@@ -825,12 +827,14 @@ __global__ __launch_bounds__(256) void k_region_fin_chain(ic_region_args a, floa
       RowFrag<DCH> t;
       if (pred) {
         const RowFrag<DCH>& m = cur.m;
+        if (!dead) {
 #pragma unroll
-        for (int j = 0; j < DCH; ++j) {
-          p.v[j].x = al * p.v[j].x + one_minus_alpha * m.v[j].x;
-          p.v[j].y = al * p.v[j].y + one_minus_alpha * m.v[j].y;
-          p.v[j].z = al * p.v[j].z + one_minus_alpha * m.v[j].z;
-          p.v[j].w = al * p.v[j].w + one_minus_alpha * m.v[j].w;
+          for (int j = 0; j < DCH; ++j) {
+            p.v[j].x = al * p.v[j].x + one_minus_alpha * m.v[j].x;
+            p.v[j].y = al * p.v[j].y + one_minus_alpha * m.v[j].y;
+            p.v[j].z = al * p.v[j].z + one_minus_alpha * m.v[j].z;
+            p.v[j].w = al * p.v[j].w + one_minus_alpha * m.v[j].w;
+          }
         }
         store_row(p, a.pred_o + off, d, lane);
       }
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(256) void k_region_fin_chain(ic_region_args a, floa
         load_row(t, var_src, d, lane);
         store_row(t, a.var_o + off, d, lane);
       }
-      dtv += 1;
+      if (!dead) dtv += 1;
       if (lane == 0) {
         a.dt_o[row] = dtv;
         if (afd) a.surprise_o[row] = surp;

@@ -44,6 +44,9 @@ FUSE_STEP = os.environ.get("IC_FUSE_STEP", "1") != "0"
 DEFER_SYNC = os.environ.get("IC_DEFER_SYNC", "1") != "0"
 # IC_POLL_SYNC=0: hipStreamSynchronize at every outer iteration instead of polling the pinned score block
 POLL_SYNC = os.environ.get("IC_POLL_SYNC", "1") != "0"
+# IC_STEER=0: the loops of a train_step are steered by the host (one wait per outer iteration) instead of
+# on the device (LoopEngine.run_steered: no wait at all); same results, for A/B timing and the equality test
+STEER = os.environ.get("IC_STEER", "1") != "0"
 
 class StructImage:
     """Per-step images of a C argument struct.  Most pointer fields of a step's arguments are
@@ -58,6 +61,7 @@ class StructImage:
         self.addr = ctypes.addressof(obj)
         self.stride = np.zeros(self.size // 8, dtype=np.int64)
         self.lin = {}
+        self.cols = {}
 
     @staticmethod
     def _offset(cls, path):
@@ -74,13 +78,22 @@ class StructImage:
         assert off % 8 == 0
         self.lin[off // 8] = (base, stride)
 
+    def column(self, path, values) -> None:
+        """Pointer-sized field `path` takes values[i] in image i (fields that do not advance linearly)."""
+        off = self._offset(type(self.obj), path)
+        assert off % 8 == 0
+        self.cols[off // 8] = np.asarray(values, dtype=np.int64)
+
     def images(self, ts) -> "np.ndarray":
         """[len(ts), words] struct images for steps ts; call after every static field is set."""
         base = np.frombuffer((ctypes.c_char * self.size).from_address(self.addr), dtype=np.int64).copy()
         stride = np.zeros_like(base)
         for w, (b0, st_) in self.lin.items():
             base[w], stride[w] = b0, st_
-        return base[None, :] + np.asarray(ts, dtype=np.int64)[:, None] * stride[None, :]
+        out = base[None, :] + np.asarray(ts, dtype=np.int64)[:, None] * stride[None, :]
+        for w, vals in self.cols.items():
+            out[:, w] = vals
+        return out
 
     def load(self, row) -> None:
         ctypes.memmove(self.addr, row.ctypes.data, self.size)
@@ -688,7 +701,8 @@ class LoopEngine:
         # per-branch scratch blocks are contiguous: branch b of a batched call uses block b
         # planner / critic scratch: one block per candidate branch (the chain runs for both branches
         # of an outer iteration before their scores say which one steers the next iteration)
-        buf = dict(ls=torch.zeros(8 * n8).pin_memory(), ws_prev=z(nb, d), motor=z(d), p_h=z(nb, d), p=z(nb, d), g_h=z(nb, 2 * d), g=z(nb, d),
+        # (steered loops: nobody on the host reads the score block while the loops run -- device memory)
+        buf = dict(ls=(z(8 * n8) if lock == "steer" else torch.zeros(8 * n8).pin_memory()), ws_prev=z(nb, d), motor=z(d), p_h=z(nb, d), p=z(nb, d), g_h=z(nb, 2 * d), g=z(nb, d),
                    c_h=z(nb, 2 * d),
                    z=z(nb, Kf + Kf * V), per_region=z(nb, R, V), probs=z(nb, V), aux=z(nb, 4), gsq=z(nb, 2 * R))
         P = {k: t.data_ptr() for k, t in buf.items()}
@@ -982,6 +996,329 @@ class LoopEngine:
         traces.append(keep(H_of(branches[0][1])))
         return branches[0][1], last, traces
 
+
+
+    # ------------------------------------------------------------------ device-steered strict loops
+    def steer_usable(self, dev, K_inner: int) -> bool:
+        """Can the loops of a reasoning_loop_batch call run with the outer-iteration decisions taken on the
+        device (run_steered)?  The branching loop with two branches, planner / critic / verifier present."""
+        m = self.model
+        cfg = m.cfg
+        if not STEER or not self.enabled or dev.type != "cuda" or K_inner < 1:
+            return False
+        if cfg.train_deterministic_inner_loop or cfg.B_br != 2 or m.plan is None or m.verify is None:
+            return False
+        if cfg.profile or cfg.ff_dropout or m.router.edge_transform_mode == "factorized" or m.router.E <= 0:
+            return False
+        return True
+
+    def _steer_bufs(self, dev, N: int, K: int, C: int):
+        """Static device buffers of the steered loops (fixed addresses from step to step: what a captured
+        launch sequence needs): per-loop inputs, the control blocks, the per-loop records."""
+        m = self.model
+        key = (dev, N, K, C, m.d, max(m.router.E, 1))
+        sb = getattr(self, "_sbufs", None)
+        if sb is not None and sb["key"] == key:
+            return sb
+        W = ENUMS["IC_CTL_WORDS"]
+        sb = dict(key=key, sens=torch.zeros(N, m.d, device=dev), fo=torch.ones(N, C, dtype=_U8, device=dev),
+                  aux=torch.zeros(N, C, 4, device=dev), ebias=torch.zeros(max(m.router.E, 1), device=dev),
+                  ctl=torch.zeros(N * K + 1, W, dtype=_I32, device=dev), rec=torch.zeros(N, 4, dtype=_I32, device=dev),
+                  vhat0=torch.zeros(1, device=dev))
+        self._sbufs = sb
+        return sb
+
+    def run_steered(self, K_inner: int, sensors: torch.Tensor, fo_all: torch.Tensor, aux_all):
+        """Strict-sequential reasoning loops of a whole batch (reference model.py:462-503 over :329-460) with NO
+        host wait inside: what the host decided between two outer iterations in _drive -- winner order, the
+        winner's critic value, uncertainty, burst, halting (model.py:371-392,440-452) -- is decided by
+        ic_loop_steer on the device and reaches the next iteration's launches through a control block
+        (per-stream indirections of the kernels).  The host queues every launch of every loop back to back;
+        an iteration behind a loop that halted is a pass-through (empty gate mask, state copied).  The loops
+        run one after the other on one stream, sample j from the region state / workspace sample j-1 left
+        behind: the reference's schedule, bit-identical to the host-steered path (tests/test_hip_steer.py).
+
+        Call between begin_batch() and the use of the results.  sensors [N,d]; fo_all [N,C] uint8; aux_all
+        [N,C,4] or None.  Returns (H [N,R,d] as ONE autograd node over `sensors` when grad is enabled,
+        masks uint8 [N,R], last logits [N,V], traces: N lazy lists)."""
+        m = self.model
+        cfg, bank, router, gate = m.cfg, m.bank, m.router, m.gate
+        dev = sensors.device
+        R, d, E = m.R, m.d, router.E
+        bt = self._batch
+        chunk, base, KC, N = bt["chunk"], bt["base"], bt["n_max"], bt["n_loops"]
+        C, K = 2, int(K_inner)
+        assert KC == K * C and N == sensors.shape[0]
+        grad = torch.is_grad_enabled()
+        Z = base - 1  # the slot before the first loop: the bank's state (begin_batch), H = 0, mask = 0, the workspace
+        f, CP, CS = chunk.fields, chunk.ptr, chunk.stride
+        L, st = lib(), stream_handle()
+        self.counters["steered"] = self.counters.get("steered", 0) + 1
+        sb = self._steer_bufs(dev, N, K, C)
+        W = ENUMS["IC_CTL_WORDS"]
+        with torch.no_grad():
+            f["H"][Z].zero_()
+            f["mask"][Z].zero_()
+            f["slots"][Z].copy_(m.work.slots.detach())
+            sb["sens"].copy_(sensors.detach())
+            sb["fo"].copy_(fo_all)
+            if aux_all is not None:
+                sb["aux"].copy_(aux_all)
+        ebias = router._cached_bias(m.reg_coords)  # (outside no_grad: requires_grad says whether the bias is trained)
+        with torch.no_grad():
+            sb["ebias"][:E].copy_(ebias.detach().reshape(-1))
+        hs = self._heads_setup(dev, C, lock="steer")
+        ha, ver, steer, HP = hs["ha"], hs["ver"], hs["steer"], hs["P"]
+        pairs_ = hs["pairs"]
+        lsp = HP["ls"]
+
+        # ---- critic value of the all-zero state (first iteration of every loop), left on the device
+        pv, self._vhat0_pending = getattr(self, "_vhat0_pending", None), None
+        if pv is not None and pv[3] == dev:
+            # new_step() queued the chain; its result sits in the pinned score block of the host-steered set-up
+            sb["vhat0"].copy_(pv[1][pv[2]:pv[2] + 1], non_blocking=True)
+        else:
+            sa = hs["sa"]
+            sa.n_cand = 1
+            sa.H_cand[0], sa.mask_cand[0] = CP["H"] + Z * CS["H"], CP["mask"] + Z * CS["mask"]
+            sa.scores = None
+            for g in steer:
+                g.nbatch = 1
+            y5 = steer[5].y
+            steer[5].y = sb["vhat0"].data_ptr()
+            rc = L.ic_steer_select(ctypes.byref(sa), st) or L.ic_gemv_chain(steer, 6, st)
+            steer[5].y = y5
+            if rc:
+                check(rc, "ic_steer_select/ic_gemv_chain")
+
+        # ---- structs: static fields once, the moving pointers as per-iteration images
+        tables = router._edge_tables(m.reg_coords)
+        kw_k, kw_soft, kw_temp = bank.kwta_now()
+        flags = bank._flags(kw_soft, bank.cells[0].disable_kwta, True)
+        rP, bP = router._params(), bank.params()
+        off, nbr = gate._tables(dev)
+        rspec = router.spec()
+        prec, afd, rt_, use_pred = rspec.precision, bank.afd, bank.rt, bank.use_pred
+        ctl_p, rec_p = sb["ctl"].data_ptr(), sb["rec"].data_ptr()
+        cw = W * 4
+        o_in, o_ws, o_kt, o_t5, o_t6, o_dead = (4 * ENUMS[k_] for k_ in (
+            "IC_CTL_IN_SLOT", "IC_CTL_SLOTS_SLOT", "IC_CTL_K_TOTAL", "IC_CTL_T5", "IC_CTL_T6", "IC_CTL_DEAD"))
+        G = N * K
+        gs = np.arange(G, dtype=np.int64)
+        a0s = base + gs * C          # slot of branch 0 of global iteration g = j * K + k
+        js, ks = gs // K, gs % K
+
+        ga = new("ic_gate_args", S=C, R=R, d=d, sensor_idx=m.io_idxs["sensor"], motor_idx=m.io_idxs["motor"],
+                 force_io=1, w1=gate.w1, w2=gate.w2, w3=gate.w3, w4=gate.w4, gain_ema=gate.gain_ema,
+                 homeo=gate.homeo, nbr_off=off, nbr=nbr)
+        ga.H = CP["H"]
+        gimg = StructImage(ga)
+        for k_ in ("scores", "mask"):
+            gimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
+        gimg.linear(("in_slot",), ctl_p + o_in, cw)
+        gimg.linear(("k_total_s",), ctl_p + o_kt, cw)
+        gimg.linear(("t5_s",), ctl_p + o_t5, cw)
+        gimg.linear(("t6_s",), ctl_p + o_t6, cw)
+        gimg.column(("focus_any",), sb["fo"].data_ptr() + js * C)
+        g_rows = gimg.images(gs)
+
+        ra = ops._router_args(rspec, tables, rP, C)
+        ra.ebias, ra.H, ra.mask_prev = sb["ebias"].data_ptr(), CP["H"], CP["mask"]
+        rimg = StructImage(ra)
+        for k_ in ["M"] + (["msg", "keyv", "q", "wgt"] if prec else []):
+            rimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
+        rimg.linear(("in_slot",), ctl_p + o_in, cw)
+        r_rows = rimg.images(gs)
+
+        P = dict(bP)
+        P["norm_in_w"] = m.norm_in.weight
+        fa = ops._region_args(bank.spec, P, C, 0.0, kw_k, flags | ENUMS["IC_F_CHAIN"], kw_temp)
+        fa.last_dir, fa.last_norm = bank.last_dir.data_ptr(), bank.last_norm.data_ptr()
+        fimg = StructImage(fa)
+        state_pairs = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o"), ("var", "var_o"), ("surprise", "surprise_o"),
+                       ("pred", "pred_o"), ("radius", "radius_o"), ("radius_var", "radius_var_o")]
+        saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
+            + (["sterm"] if afd else [])
+        for k_ in ["M", "mask", "H"] + saved:
+            fimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
+        for k_, ko in state_pairs:
+            if ko in CP:  # state in = what the slot before left; out = this iteration's slots
+                fimg.linear((k_,), CP[ko] + (base - 1) * CS[ko], C * CS[ko])
+                fimg.linear((ko,), CP[ko] + base * CS[ko], C * CS[ko])
+        fimg.linear(("dead",), ctl_p + o_dead, cw)
+        fimg.column(("sensor",), sb["sens"].data_ptr() + js * (d * 4))
+        f_rows = fimg.images(gs)
+        denom = float(max(1, cfg.K_inner - 1))
+
+        aux_on = ver is not None and m.verify.aux_dim > 0
+        aux_p = sb["aux"].data_ptr()
+        ha.S, ha.Hpar_sstride, ha.slots_in_sstride = C, 0, 0
+        ha.H_par, ha.slots_in = CP["H"], CP["slots"]
+        ha.stats = lsp + 8 * 4
+        himg = StructImage(ha)
+        for k_, fld in (("H", "H"), ("mask", "mask"), ("slots", "slots_out"), ("logits", "logits")):
+            himg.linear((fld,), CP[k_] + base * CS[k_], C * CS[k_])
+        if afd:
+            himg.linear(("surprise",), CP["surprise_o"] + base * CS["surprise_o"], C * CS["surprise_o"])
+        else:
+            ha.surprise = None
+        himg.linear(("par_slot",), ctl_p + o_in, cw)
+        himg.linear(("slots_slot",), ctl_p + o_ws, cw)
+        himg.column(("aux_surprise",), (aux_p + js * (C * 16) + 4) if aux_on else np.zeros(G, dtype=np.int64))
+        himg.column(("ws_mean",), np.where(ks < K - 1, HP["ws_prev"], 0))  # the planner rides unless the loop ends here
+        h_rows = himg.images(gs)
+
+        motor = m.io_idxs["motor"]
+        for g_ in ver:
+            g_.nbatch = C
+        for g_ in steer:
+            g_.nbatch = C
+        ver[2].y = lsp + 48 * 4
+        for i_ in range(3):
+            pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_ + 2]
+        crit = m.critic.mlp.net[2]
+        la = new("ic_loop_steer_args", C=C, R=R, k_active=cfg.k_active, K_inner=K, zero_slot=Z, w5=float(gate.w5),
+                 w6=float(gate.w6), vhat=lsp + 40 * 4, scores=lsp, stats=lsp + 8 * 4, vhat0=sb["vhat0"].data_ptr())
+        cW, cb, cx, ccols = crit.weight.data_ptr(), crit.bias.data_ptr(), HP["c_h"], int(crit.weight.shape[1])
+        la_ref = ctypes.byref(la)
+        la.mode, la.ctl_next = ENUMS["IC_STEER_INIT"], ctl_p
+        rc = L.ic_loop_steer(la_ref, st)
+        if rc:
+            check(rc, "ic_loop_steer")
+        la.crit_x, la.crit_cols = cx, ccols
+        STEP, LAST = ENUMS["IC_STEER_STEP"], ENUMS["IC_STEER_LAST"]
+        ga_ref, ra_ref, fa_ref, ha_ref = ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(fa), ctypes.byref(ha)
+        s0_ref, s1_ref = ctypes.byref(steer[0]), ctypes.byref(steer[1])
+        step_fwd, heads_gemv, heads_fwd, multi, vscore, steer_fn = (L.ic_loop_step_fwd, L.ic_heads_gemv_fwd, L.ic_heads_fwd,
+                                                                     L.ic_gemv_multi, L.ic_verify_score, L.ic_loop_steer)
+        Hm = CP["H"] + motor * d * 4
+        HS = CS["H"]
+        g = 0
+        for j in range(N):
+            ax = aux_p + j * (C * 16)
+            ver[0].x2 = ax
+            pairs_[0][0].x2 = ax
+            la.rec = rec_p + j * 16
+            for k in range(K):
+                a0 = base + g * C
+                gimg.load(g_rows[g])
+                rimg.load(r_rows[g])
+                fimg.load(f_rows[g])
+                fa.step_pos = float(k) / denom
+                rc = step_fwd(ga_ref, ra_ref, fa_ref, st)
+                if rc:
+                    check(rc, "ic_loop_step_fwd")
+                himg.load(h_rows[g])
+                x0 = Hm + a0 * HS
+                la.k, la.slot0, la.ctl = k, a0, ctl_p + g * cw
+                if k < K - 1:
+                    rc = heads_gemv(ha_ref, s0_ref, s1_ref, st)
+                    if rc:
+                        check(rc, "ic_heads_gemv_fwd")
+                    pairs_[0][0].x0 = x0
+                    rc = (multi(pairs_[0], 2, lsp + 8 * 4, None, st) or multi(pairs_[1], 2, lsp + 8 * 4, None, st)
+                          or multi(pairs_[2], 2, lsp + 8 * 4, lsp, st))
+                    if rc:
+                        check(rc, "ic_gemv_multi")
+                    la.mode, la.crit_W, la.crit_b, la.ctl_next = STEP, cW, cb, ctl_p + (g + 1) * cw
+                else:
+                    rc = heads_fwd(ha_ref, st)
+                    if rc:
+                        check(rc, "ic_heads_fwd")
+                    ver[0].x0 = x0
+                    rc = vscore(ver, 3, lsp + 8 * 4, lsp, st)
+                    if rc:
+                        check(rc, "ic_verify_score")
+                    la.mode, la.crit_W, la.crit_b = LAST, None, None
+                    la.ctl_next = ctl_p + (g + 1) * cw  # (the block after the last loop's is never read)
+                rc = steer_fn(la_ref, st)
+                if rc:
+                    check(rc, "ic_loop_steer")
+                g += 1
+
+        # ---- results, gathered on the device through the loops' records: nothing here waits for the GPU
+        with torch.no_grad():
+            recl = sb["rec"].long()
+            bslot, lslot = recl[:, 0], recl[:, 1]
+            H_out = f["H"].index_select(0, bslot)
+            masks = f["mask"].index_select(0, bslot)
+            logits = f["logits"].index_select(0, lslot)
+            li = base + N * KC - 1  # (halted loops pass their state through to their block's last slot)
+            nar = torch.narrow
+            bank.num, bank.den, bank.dt = nar(f["num_o"], 0, li, 1), nar(f["den_o"], 0, li, 1), nar(f["dt_o"], 0, li, 1)
+            if afd:
+                bank.var, bank.surprise = nar(f["var_o"], 0, li, 1), nar(f["surprise_o"], 0, li, 1)
+            if use_pred:
+                bank.pred = nar(f["pred_o"], 0, li, 1)
+            if rt_:
+                bank.radius, bank.radius_var = nar(f["radius_o"], 0, li, 1), nar(f["radius_var_o"], 0, li, 1)
+            if prec:
+                router._last_wgt = f["wgt"].index_select(0, lslot[N - 1:N])[:, :E]
+            m.work.slots = f["slots"].index_select(0, bslot[N - 1:N])[0]
+        self._state_in_arena = True
+        bt["steered"] = dict(sb=sb, K=K, C=C, Z=Z, flags=flags, kwta_k=kw_k, kwta_temp=kw_temp, keep=(sb["fo"], tables, rP, bP),
+                             ebias_grad=bool(ebias.requires_grad), norm_in_w=m.norm_in.weight, denom=denom)
+        traces = [SteeredTraces(self, bt, j) for j in range(N)]
+        if not grad:  # nothing may refer to the arena afterwards: the traces are copies
+            traces = [[t.clone() for t in tr] for tr in traces]
+            self._batch = None
+            self._rescue_state()
+            return H_out, masks, logits, traces
+        bt["H_out"] = H_out
+        self._batch = None
+        H = LoopBatchFn.apply(sensors, bank.anchor(dev), self, bt)
+        return H, masks, logits, traces
+
+    def resolve_steered(self, bt) -> None:
+        """Host-side record of the steered loops of a batch (the backward's parents and winners, traces, counters):
+        ONE read of the control blocks the device wrote, after the loops ran."""
+        sp = bt.pop("steered", None)
+        if sp is None:
+            return
+        m = self.model
+        sb, K, C, Z = sp["sb"], sp["K"], sp["C"], sp["Z"]
+        chunk, base, KC, N = bt["chunk"], bt["base"], bt["n_max"], bt["n_loops"]
+        f = chunk.fields
+        ctl = sb["ctl"].cpu().numpy()  # (waits for the stream)
+        rec = sb["rec"].cpu().numpy()
+        DEAD, TOP, VH = ENUMS["IC_CTL_DEAD"], ENUMS["IC_CTL_TOP"], ENUMS["IC_CTL_VHAT"]
+        samples, n_inner = [], 0
+        step_pos_all = [float(t // C) / sp["denom"] for t in range(KC)]
+        for j in range(N):
+            i0 = base + j * KC
+            parent: List[int] = []
+            n_it = 0
+            for k in range(K):
+                blk = ctl[j * K + k]
+                if blk[DEAD]:
+                    break
+                if k == 0:
+                    parent += [-1] * C
+                else:
+                    t0_ = int(blk[TOP])
+                    parent += [(k - 1) * C + t0_, (k - 1) * C + (1 - t0_)]
+                n_it += 1
+            n = n_it * C
+            assert n == int(rec[j, 2]) and n_it == int(rec[j, 3]), (j, n, rec[j])
+            n_inner += n
+            s = _Sample()
+            s.chunk, s.i0, s.ts, s.n, s.parent, s.best = chunk, i0, 1, n, parent, int(rec[j, 0]) - i0
+            s.step_pos = step_pos_all[:n]
+            s.init = {k_: f[ko][i0 - 1] for k_, ko in (("num", "num_o"), ("den", "den_o"), ("var", "var_o"), ("pred", "pred_o"),
+                                                     ("radius", "radius_o"), ("radius_var", "radius_var_o"),
+                                                     ("surprise", "surprise_o"), ("dt", "dt_o")) if ko in f}
+            s.H0, s.mask0 = f["H"][Z:Z + 1], f["mask"][Z:Z + 1]
+            s.sensor, s.ebias, s.norm_in_w = sb["sens"][j], sb["ebias"], sp["norm_in_w"]
+            s.flags, s.kwta_k, s.kwta_temp = sp["flags"], sp["kwta_k"], sp["kwta_temp"]
+            s.keep, s.ebias_grad, s.zero_in = sp["keep"], sp["ebias_grad"], True
+            samples.append(s)
+            if m._units is not None:
+                self._unit_log.append((chunk, i0, list(parent), f["mask"][Z]))
+        bt["samples"] = samples
+        m.counters["inner_steps"] += n_inner
+        # what the host-steered loop leaves in the gate: the critic value its last iteration ran with
+        last = ctl[(N - 1) * K + max(0, int(rec[N - 1, 3]) - 1)]
+        m.gate.value_bias = float(np.array([last[VH]], dtype=np.int32).view(np.float32)[0])
 
     # ------------------------------------------------------------------ multi-stream mode (lockstep loops)
     MAX_LOCKSTEP_STREAMS = 64  # ic_heads_fwd takes at most 64 streams per launch
@@ -1843,6 +2180,35 @@ class LoopEngine:
                 accumulate(router.beta_sin, g_eb @ sinS)
 
 
+class SteeredTraces:
+    """Traces of one device-steered loop (the winner's states of every executed outer iteration, reference
+    model.py:402): a list that is filled on first use, when the loops' record is read from the device."""
+
+    def __init__(self, engine, bt, j):
+        self._src = (engine, bt, j)
+        self._items = None
+
+    def _get(self):
+        if self._items is None:
+            eng, bt, j = self._src
+            eng.resolve_steered(bt)
+            s = bt["samples"][j]
+            C = 2
+            wins = [s.parent[k * C] for k in range(1, s.n // C)] + [s.best]
+            Hf = s.chunk.fields["H"]
+            self._items = [Hf[s.i0 + w] for w in wins]
+        return self._items
+
+    def __len__(self):
+        return len(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+
 class LoopFn(torch.autograd.Function):
     """One autograd node per reasoning loop: forward hands out the loop's final region states
     (already computed by LoopEngine.run), backward replays the recorded steps in reverse."""
@@ -1876,6 +2242,7 @@ class LoopBatchFn(torch.autograd.Function):
     def backward(ctx, gH):
         eng, bt = ctx.engine, ctx.bt
         gH = gH.contiguous()
+        eng.resolve_steered(bt)  # (device-steered loops: their record is read here, once)
         if bt.get("lockstep") or eng._batch_uniform(bt):
             eng.counters["batch_bwd"] += 1
             g = eng.backward_batch(bt, gH)

@@ -492,6 +492,24 @@ class CortexReasoner(FastAttrs, nn.Module):
                     if batched[2] is not None:
                         aux_all[:, :, 2] = batched[2].detach().reshape(N, 1).to(dev)
             # rows of the per-batch tensors: one unbind each instead of an indexing op per loop
+            steer = fo_all is not None and eng.steer_usable(dev, K_inner) and (one_node or not torch.is_grad_enabled())
+            if steer:
+                # every loop of the batch queued back to back, the outer-iteration decisions taken on the device
+                self.detach_state()
+                if not one_node:  # no-grad call: nothing is kept from earlier loops
+                    eng.reset()
+                    eng.begin_batch(N, K_inner * max(1, self.cfg.B_br), dev)
+                self.router.begin_loop()
+                try:
+                    H, mk, lg, tr = eng.run_steered(K_inner, batched[0], fo_all, aux_all)
+                finally:
+                    self.router.end_loop()
+                en, ent = batched[1], batched[2]
+                self.local_mix.last_energy = en[-1]
+                if ent is not None:
+                    self.local_mix.attn.last_attn_entropy = ent[-1]
+                A = ent.detach().to(dev) if ent is not None else torch.zeros(N, device=dev)
+                return H, mk.bool(), lg, tr, en.detach(), A
             rows = lambda t: t.unbind(0) if t is not None else None
             fo_r, aux_r = rows(fo_all), rows(aux_all)
             sv_r, en_r, ent_r = (rows(batched[0]), rows(batched[1]), rows(batched[2])) if batched is not None else (None,) * 3
