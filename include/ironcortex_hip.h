@@ -516,6 +516,22 @@ typedef struct ic_loop_steer_args {
 } ic_loop_steer_args;
 int ic_loop_steer(const ic_loop_steer_args* a, ic_stream_t stream);
 
+/* ------------------------------------------------------------------ launch sequences as HIP graphs
+ * No counterpart in the reference (its loop takes a host decision per outer iteration, model.py:371-452).  With
+ * ic_loop_steer no launch of a batch's reasoning loops depends on a host value, so the whole sequence (~1300
+ * launches per train_step of the 10M config) is captured once and replayed with one call per step.
+ *   ic_graph_begin(stream)            start capturing the library calls made on `stream` (a stream of the caller's own,
+ *                                     not the default stream); nothing runs until the graph is launched
+ *   ic_graph_end(stream, &exec, &n)   stop capturing, instantiate; n (may be NULL) receives the number of nodes
+ *   ic_graph_launch(exec, stream)     run the captured sequence on `stream` (any stream, stream-ordered as usual)
+ *   ic_graph_destroy(exec)
+ * The kernel arguments (device pointers, shapes) are frozen at capture: the caller replays a graph only while
+ * every pointer it handed over is unchanged.  Profiling (ic_prof_enable) must be off while capturing. */
+int ic_graph_begin(ic_stream_t stream);
+int ic_graph_end(ic_stream_t stream, void** exec_out, int32_t* n_nodes);
+int ic_graph_launch(void* exec, ic_stream_t stream);
+int ic_graph_destroy(void* exec);
+
 /* ------------------------------------------------------------------ measurement hooks
  * No counterpart in the reference (its cfg.profile timers read perf_counter without a device
  * sync, model.py:219-294).  When enabled every kernel launch of this library is bracketed by

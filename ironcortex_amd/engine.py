@@ -31,6 +31,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
+from . import hip as hip_mod
 from .hip import CLASSES, ENUMS, check, lib, new, ops, stream_handle
 from .utils import schedule_burst, should_halt
 
@@ -47,6 +48,8 @@ POLL_SYNC = os.environ.get("IC_POLL_SYNC", "1") != "0"
 # IC_STEER=0: the loops of a train_step are steered by the host (one wait per outer iteration) instead of
 # on the device (LoopEngine.run_steered: no wait at all); same results, for A/B timing and the equality test
 STEER = os.environ.get("IC_STEER", "1") != "0"
+# IC_GRAPH=0: the steered loops are launched call by call every step instead of replayed as one captured HIP graph
+GRAPH = os.environ.get("IC_GRAPH", "1") != "0"
 
 class StructImage:
     """Per-step images of a C argument struct.  Most pointer fields of a step's arguments are
@@ -175,6 +178,8 @@ class LoopEngine:
         self._pending = None
         self._events = None
         self._wsb = None
+        self._graph = None       # captured launch sequence of the steered loops (run_steered)
+        self._cap_stream = None
         self.counters = {"batch_bwd": 0, "loop_bwd": 0, "lockstep": 0}  # backward passes taken all-loops-at-once / loop by loop
         model._coord.register(self._begin_pass, self._finish_pass)
 
@@ -999,6 +1004,11 @@ class LoopEngine:
 
 
     # ------------------------------------------------------------------ device-steered strict loops
+    def _drop_graph(self) -> None:
+        gr, self._graph = self._graph, None
+        if gr is not None:
+            lib().ic_graph_destroy(gr["exec"])
+
     def steer_usable(self, dev, K_inner: int) -> bool:
         """Can the loops of a reasoning_loop_batch call run with the outer-iteration decisions taken on the
         device (run_steered)?  The branching loop with two branches, planner / critic / verifier present."""
@@ -1091,150 +1101,198 @@ class LoopEngine:
             if rc:
                 check(rc, "ic_steer_select/ic_gemv_chain")
 
-        # ---- structs: static fields once, the moving pointers as per-iteration images
+        # ---- everything the launches depend on: pointers and scalars that end up in kernel arguments
         tables = router._edge_tables(m.reg_coords)
         kw_k, kw_soft, kw_temp = bank.kwta_now()
         flags = bank._flags(kw_soft, bank.cells[0].disable_kwta, True)
         rP, bP = router._params(), bank.params()
-        off, nbr = gate._tables(dev)
         rspec = router.spec()
         prec, afd, rt_, use_pred = rspec.precision, bank.afd, bank.rt, bank.use_pred
-        ctl_p, rec_p = sb["ctl"].data_ptr(), sb["rec"].data_ptr()
-        cw = W * 4
-        o_in, o_ws, o_kt, o_t5, o_t6, o_dead = (4 * ENUMS[k_] for k_ in (
-            "IC_CTL_IN_SLOT", "IC_CTL_SLOTS_SLOT", "IC_CTL_K_TOTAL", "IC_CTL_T5", "IC_CTL_T6", "IC_CTL_DEAD"))
-        G = N * K
-        gs = np.arange(G, dtype=np.int64)
-        a0s = base + gs * C          # slot of branch 0 of global iteration g = j * K + k
-        js, ks = gs // K, gs % K
-
-        ga = new("ic_gate_args", S=C, R=R, d=d, sensor_idx=m.io_idxs["sensor"], motor_idx=m.io_idxs["motor"],
-                 force_io=1, w1=gate.w1, w2=gate.w2, w3=gate.w3, w4=gate.w4, gain_ema=gate.gain_ema,
-                 homeo=gate.homeo, nbr_off=off, nbr=nbr)
-        ga.H = CP["H"]
-        gimg = StructImage(ga)
-        for k_ in ("scores", "mask"):
-            gimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
-        gimg.linear(("in_slot",), ctl_p + o_in, cw)
-        gimg.linear(("k_total_s",), ctl_p + o_kt, cw)
-        gimg.linear(("t5_s",), ctl_p + o_t5, cw)
-        gimg.linear(("t6_s",), ctl_p + o_t6, cw)
-        gimg.column(("focus_any",), sb["fo"].data_ptr() + js * C)
-        g_rows = gimg.images(gs)
-
-        ra = ops._router_args(rspec, tables, rP, C)
-        ra.ebias, ra.H, ra.mask_prev = sb["ebias"].data_ptr(), CP["H"], CP["mask"]
-        rimg = StructImage(ra)
-        for k_ in ["M"] + (["msg", "keyv", "q", "wgt"] if prec else []):
-            rimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
-        rimg.linear(("in_slot",), ctl_p + o_in, cw)
-        r_rows = rimg.images(gs)
-
-        P = dict(bP)
-        P["norm_in_w"] = m.norm_in.weight
-        fa = ops._region_args(bank.spec, P, C, 0.0, kw_k, flags | ENUMS["IC_F_CHAIN"], kw_temp)
-        fa.last_dir, fa.last_norm = bank.last_dir.data_ptr(), bank.last_norm.data_ptr()
-        fimg = StructImage(fa)
-        state_pairs = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o"), ("var", "var_o"), ("surprise", "surprise_o"),
-                       ("pred", "pred_o"), ("radius", "radius_o"), ("radius_var", "radius_var_o")]
-        saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
-            + (["sterm"] if afd else [])
-        for k_ in ["M", "mask", "H"] + saved:
-            fimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
-        for k_, ko in state_pairs:
-            if ko in CP:  # state in = what the slot before left; out = this iteration's slots
-                fimg.linear((k_,), CP[ko] + (base - 1) * CS[ko], C * CS[ko])
-                fimg.linear((ko,), CP[ko] + base * CS[ko], C * CS[ko])
-        fimg.linear(("dead",), ctl_p + o_dead, cw)
-        fimg.column(("sensor",), sb["sens"].data_ptr() + js * (d * 4))
-        f_rows = fimg.images(gs)
         denom = float(max(1, cfg.K_inner - 1))
+        dp_ = lambda ts: tuple(t.data_ptr() for t in ts if torch.is_tensor(t))
+        key = (tuple(CP.values()), base, N, K, R, d, E, flags, kw_k, kw_temp, cfg.k_active, cfg.K_inner, hs["key"],
+               tuple(HP.values()), dp_(tables.values()), dp_(sb.values()), dp_(gate._tables(dev)), dp_(rP.values()),
+               dp_(bP.values()), m.norm_in.weight.data_ptr(), gate.gain_ema.data_ptr(), gate.homeo.data_ptr(),
+               bank.last_dir.data_ptr(), bank.last_norm.data_ptr(), (gate.w1, gate.w2, gate.w3, gate.w4, gate.w5, gate.w6),
+               (rspec.R, rspec.d, rspec.E, rspec.nW, rspec.precision, rspec.shared_gemm), m.io_idxs["sensor"], m.io_idxs["motor"])
 
-        aux_on = ver is not None and m.verify.aux_dim > 0
-        aux_p = sb["aux"].data_ptr()
-        ha.S, ha.Hpar_sstride, ha.slots_in_sstride = C, 0, 0
-        ha.H_par, ha.slots_in = CP["H"], CP["slots"]
-        ha.stats = lsp + 8 * 4
-        himg = StructImage(ha)
-        for k_, fld in (("H", "H"), ("mask", "mask"), ("slots", "slots_out"), ("logits", "logits")):
-            himg.linear((fld,), CP[k_] + base * CS[k_], C * CS[k_])
-        if afd:
-            himg.linear(("surprise",), CP["surprise_o"] + base * CS["surprise_o"], C * CS["surprise_o"])
-        else:
-            ha.surprise = None
-        himg.linear(("par_slot",), ctl_p + o_in, cw)
-        himg.linear(("slots_slot",), ctl_p + o_ws, cw)
-        himg.column(("aux_surprise",), (aux_p + js * (C * 16) + 4) if aux_on else np.zeros(G, dtype=np.int64))
-        himg.column(("ws_mean",), np.where(ks < K - 1, HP["ws_prev"], 0))  # the planner rides unless the loop ends here
-        h_rows = himg.images(gs)
+        def build():
+            """C structs of the batch's launches: static fields once, the moving pointers as per-iteration images."""
+            off, nbr = gate._tables(dev)
+            ctl_p, rec_p = sb["ctl"].data_ptr(), sb["rec"].data_ptr()
+            cw = W * 4
+            o_in, o_ws, o_kt, o_t5, o_t6, o_dead = (4 * ENUMS[k_] for k_ in (
+                "IC_CTL_IN_SLOT", "IC_CTL_SLOTS_SLOT", "IC_CTL_K_TOTAL", "IC_CTL_T5", "IC_CTL_T6", "IC_CTL_DEAD"))
+            G = N * K
+            gs = np.arange(G, dtype=np.int64)
+            a0s = base + gs * C          # slot of branch 0 of global iteration g = j * K + k
+            js, ks = gs // K, gs % K
 
-        motor = m.io_idxs["motor"]
-        for g_ in ver:
-            g_.nbatch = C
-        for g_ in steer:
-            g_.nbatch = C
-        ver[2].y = lsp + 48 * 4
-        for i_ in range(3):
-            pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_ + 2]
-        crit = m.critic.mlp.net[2]
-        la = new("ic_loop_steer_args", C=C, R=R, k_active=cfg.k_active, K_inner=K, zero_slot=Z, w5=float(gate.w5),
-                 w6=float(gate.w6), vhat=lsp + 40 * 4, scores=lsp, stats=lsp + 8 * 4, vhat0=sb["vhat0"].data_ptr())
-        cW, cb, cx, ccols = crit.weight.data_ptr(), crit.bias.data_ptr(), HP["c_h"], int(crit.weight.shape[1])
-        la_ref = ctypes.byref(la)
-        la.mode, la.ctl_next = ENUMS["IC_STEER_INIT"], ctl_p
-        rc = L.ic_loop_steer(la_ref, st)
-        if rc:
-            check(rc, "ic_loop_steer")
-        la.crit_x, la.crit_cols = cx, ccols
-        STEP, LAST = ENUMS["IC_STEER_STEP"], ENUMS["IC_STEER_LAST"]
-        ga_ref, ra_ref, fa_ref, ha_ref = ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(fa), ctypes.byref(ha)
-        s0_ref, s1_ref = ctypes.byref(steer[0]), ctypes.byref(steer[1])
-        step_fwd, heads_gemv, heads_fwd, multi, vscore, steer_fn = (L.ic_loop_step_fwd, L.ic_heads_gemv_fwd, L.ic_heads_fwd,
-                                                                     L.ic_gemv_multi, L.ic_verify_score, L.ic_loop_steer)
-        Hm = CP["H"] + motor * d * 4
-        HS = CS["H"]
-        g = 0
-        for j in range(N):
-            ax = aux_p + j * (C * 16)
-            ver[0].x2 = ax
-            pairs_[0][0].x2 = ax
-            la.rec = rec_p + j * 16
-            for k in range(K):
-                a0 = base + g * C
-                gimg.load(g_rows[g])
-                rimg.load(r_rows[g])
-                fimg.load(f_rows[g])
-                fa.step_pos = float(k) / denom
-                rc = step_fwd(ga_ref, ra_ref, fa_ref, st)
-                if rc:
-                    check(rc, "ic_loop_step_fwd")
-                himg.load(h_rows[g])
-                x0 = Hm + a0 * HS
-                la.k, la.slot0, la.ctl = k, a0, ctl_p + g * cw
-                if k < K - 1:
-                    rc = heads_gemv(ha_ref, s0_ref, s1_ref, st)
-                    if rc:
-                        check(rc, "ic_heads_gemv_fwd")
-                    pairs_[0][0].x0 = x0
-                    rc = (multi(pairs_[0], 2, lsp + 8 * 4, None, st) or multi(pairs_[1], 2, lsp + 8 * 4, None, st)
-                          or multi(pairs_[2], 2, lsp + 8 * 4, lsp, st))
-                    if rc:
-                        check(rc, "ic_gemv_multi")
-                    la.mode, la.crit_W, la.crit_b, la.ctl_next = STEP, cW, cb, ctl_p + (g + 1) * cw
-                else:
-                    rc = heads_fwd(ha_ref, st)
-                    if rc:
-                        check(rc, "ic_heads_fwd")
-                    ver[0].x0 = x0
-                    rc = vscore(ver, 3, lsp + 8 * 4, lsp, st)
-                    if rc:
-                        check(rc, "ic_verify_score")
-                    la.mode, la.crit_W, la.crit_b = LAST, None, None
-                    la.ctl_next = ctl_p + (g + 1) * cw  # (the block after the last loop's is never read)
-                rc = steer_fn(la_ref, st)
+            ga = new("ic_gate_args", S=C, R=R, d=d, sensor_idx=m.io_idxs["sensor"], motor_idx=m.io_idxs["motor"],
+                     force_io=1, w1=gate.w1, w2=gate.w2, w3=gate.w3, w4=gate.w4, gain_ema=gate.gain_ema,
+                     homeo=gate.homeo, nbr_off=off, nbr=nbr)
+            ga.H = CP["H"]
+            gimg = StructImage(ga)
+            for k_ in ("scores", "mask"):
+                gimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
+            gimg.linear(("in_slot",), ctl_p + o_in, cw)
+            gimg.linear(("k_total_s",), ctl_p + o_kt, cw)
+            gimg.linear(("t5_s",), ctl_p + o_t5, cw)
+            gimg.linear(("t6_s",), ctl_p + o_t6, cw)
+            gimg.column(("focus_any",), sb["fo"].data_ptr() + js * C)
+            g_rows = gimg.images(gs)
+
+            ra = ops._router_args(rspec, tables, rP, C)
+            ra.ebias, ra.H, ra.mask_prev = sb["ebias"].data_ptr(), CP["H"], CP["mask"]
+            rimg = StructImage(ra)
+            for k_ in ["M"] + (["msg", "keyv", "q", "wgt"] if prec else []):
+                rimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
+            rimg.linear(("in_slot",), ctl_p + o_in, cw)
+            r_rows = rimg.images(gs)
+
+            P = dict(bP)
+            P["norm_in_w"] = m.norm_in.weight
+            fa = ops._region_args(bank.spec, P, C, 0.0, kw_k, flags | ENUMS["IC_F_CHAIN"], kw_temp)
+            fa.last_dir, fa.last_norm = bank.last_dir.data_ptr(), bank.last_norm.data_ptr()
+            fimg = StructImage(fa)
+            state_pairs = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o"), ("var", "var_o"), ("surprise", "surprise_o"),
+                           ("pred", "pred_o"), ("radius", "radius_o"), ("radius_var", "radius_var_o")]
+            saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
+                + (["sterm"] if afd else [])
+            for k_ in ["M", "mask", "H"] + saved:
+                fimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
+            for k_, ko in state_pairs:
+                if ko in CP:  # state in = what the slot before left; out = this iteration's slots
+                    fimg.linear((k_,), CP[ko] + (base - 1) * CS[ko], C * CS[ko])
+                    fimg.linear((ko,), CP[ko] + base * CS[ko], C * CS[ko])
+            fimg.linear(("dead",), ctl_p + o_dead, cw)
+            fimg.column(("sensor",), sb["sens"].data_ptr() + js * (d * 4))
+            f_rows = fimg.images(gs)
+
+            aux_on = ver is not None and m.verify.aux_dim > 0
+            aux_p = sb["aux"].data_ptr()
+            ha.S, ha.Hpar_sstride, ha.slots_in_sstride = C, 0, 0
+            ha.H_par, ha.slots_in = CP["H"], CP["slots"]
+            ha.stats = lsp + 8 * 4
+            himg = StructImage(ha)
+            for k_, fld in (("H", "H"), ("mask", "mask"), ("slots", "slots_out"), ("logits", "logits")):
+                himg.linear((fld,), CP[k_] + base * CS[k_], C * CS[k_])
+            if afd:
+                himg.linear(("surprise",), CP["surprise_o"] + base * CS["surprise_o"], C * CS["surprise_o"])
+            else:
+                ha.surprise = None
+            himg.linear(("par_slot",), ctl_p + o_in, cw)
+            himg.linear(("slots_slot",), ctl_p + o_ws, cw)
+            himg.column(("aux_surprise",), (aux_p + js * (C * 16) + 4) if aux_on else np.zeros(G, dtype=np.int64))
+            himg.column(("ws_mean",), np.where(ks < K - 1, HP["ws_prev"], 0))  # the planner rides unless the loop ends here
+            h_rows = himg.images(gs)
+
+            motor = m.io_idxs["motor"]
+            for g_ in ver:
+                g_.nbatch = C
+            for g_ in steer:
+                g_.nbatch = C
+            ver[2].y = lsp + 48 * 4
+            for i_ in range(3):
+                pairs_[i_][0], pairs_[i_][1] = ver[i_], steer[i_ + 2]
+            crit = m.critic.mlp.net[2]
+            la = new("ic_loop_steer_args", C=C, R=R, k_active=cfg.k_active, K_inner=K, zero_slot=Z, w5=float(gate.w5),
+                     w6=float(gate.w6), vhat=lsp + 40 * 4, scores=lsp, stats=lsp + 8 * 4, vhat0=sb["vhat0"].data_ptr())
+            cW, cb, cx, ccols = crit.weight.data_ptr(), crit.bias.data_ptr(), HP["c_h"], int(crit.weight.shape[1])
+            la_ref = ctypes.byref(la)
+
+            def launch_all(st) -> None:
+                """Every launch of the batch on stream st: the first control block, then loop after loop."""
+                la.mode, la.ctl_next = ENUMS["IC_STEER_INIT"], ctl_p
+                rc = L.ic_loop_steer(la_ref, st)
                 if rc:
                     check(rc, "ic_loop_steer")
-                g += 1
+                la.crit_x, la.crit_cols = cx, ccols
+                STEP, LAST = ENUMS["IC_STEER_STEP"], ENUMS["IC_STEER_LAST"]
+                ga_ref, ra_ref, fa_ref, ha_ref = ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(fa), ctypes.byref(ha)
+                s0_ref, s1_ref = ctypes.byref(steer[0]), ctypes.byref(steer[1])
+                step_fwd, heads_gemv, heads_fwd, multi, vscore, steer_fn = (L.ic_loop_step_fwd, L.ic_heads_gemv_fwd, L.ic_heads_fwd,
+                                                                             L.ic_gemv_multi, L.ic_verify_score, L.ic_loop_steer)
+                Hm = CP["H"] + motor * d * 4
+                HS = CS["H"]
+                g = 0
+                for j in range(N):
+                    ax = aux_p + j * (C * 16)
+                    ver[0].x2 = ax
+                    pairs_[0][0].x2 = ax
+                    la.rec = rec_p + j * 16
+                    for k in range(K):
+                        a0 = base + g * C
+                        gimg.load(g_rows[g])
+                        rimg.load(r_rows[g])
+                        fimg.load(f_rows[g])
+                        fa.step_pos = float(k) / denom
+                        rc = step_fwd(ga_ref, ra_ref, fa_ref, st)
+                        if rc:
+                            check(rc, "ic_loop_step_fwd")
+                        himg.load(h_rows[g])
+                        x0 = Hm + a0 * HS
+                        la.k, la.slot0, la.ctl = k, a0, ctl_p + g * cw
+                        if k < K - 1:
+                            rc = heads_gemv(ha_ref, s0_ref, s1_ref, st)
+                            if rc:
+                                check(rc, "ic_heads_gemv_fwd")
+                            pairs_[0][0].x0 = x0
+                            rc = (multi(pairs_[0], 2, lsp + 8 * 4, None, st) or multi(pairs_[1], 2, lsp + 8 * 4, None, st)
+                                  or multi(pairs_[2], 2, lsp + 8 * 4, lsp, st))
+                            if rc:
+                                check(rc, "ic_gemv_multi")
+                            la.mode, la.crit_W, la.crit_b, la.ctl_next = STEP, cW, cb, ctl_p + (g + 1) * cw
+                        else:
+                            rc = heads_fwd(ha_ref, st)
+                            if rc:
+                                check(rc, "ic_heads_fwd")
+                            ver[0].x0 = x0
+                            rc = vscore(ver, 3, lsp + 8 * 4, lsp, st)
+                            if rc:
+                                check(rc, "ic_verify_score")
+                            la.mode, la.crit_W, la.crit_b = LAST, None, None
+                            la.ctl_next = ctl_p + (g + 1) * cw  # (the block after the last loop's is never read)
+                        rc = steer_fn(la_ref, st)
+                        if rc:
+                            check(rc, "ic_loop_steer")
+                        g += 1
+
+
+            return launch_all
+
+        use_graph = GRAPH and not hip_mod.PROF_ON
+        gr = self._graph
+        if use_graph and gr is not None and gr["key"] == key:
+            rc = L.ic_graph_launch(gr["exec"], st)  # the same launch sequence as last step: one call
+            if rc:
+                check(rc, "ic_graph_launch")
+        elif use_graph:
+            # capture the sequence once (on a stream of its own: the default stream cannot be captured), then replay it
+            self._drop_graph()
+            launch_all = build()
+            cs = self._cap_stream
+            if cs is None or cs.device != dev:
+                cs = self._cap_stream = torch.cuda.Stream(dev)
+            ex, nn = ctypes.c_void_p(), ctypes.c_int32(0)
+            with torch.cuda.stream(cs):
+                h = stream_handle()
+                rc = L.ic_graph_begin(h)
+                if rc:
+                    check(rc, "ic_graph_begin")
+                try:
+                    launch_all(h)
+                finally:
+                    rc = L.ic_graph_end(h, ctypes.byref(ex), ctypes.byref(nn))
+                if rc:
+                    check(rc, "ic_graph_end")
+            self._graph = {"key": key, "exec": ex, "nodes": nn.value}
+            self.counters["graph_captures"] = self.counters.get("graph_captures", 0) + 1
+            rc = L.ic_graph_launch(ex, st)
+            if rc:
+                check(rc, "ic_graph_launch")
+        else:
+            build()(st)
 
         # ---- results, gathered on the device through the loops' records: nothing here waits for the GPU
         with torch.no_grad():

@@ -109,6 +109,10 @@ def lib():
         _lib.ic_loop_step_fwd.argtypes = [vp, vp, vp, vp]
         _lib.ic_heads_gemv_fwd.argtypes = [vp, vp, vp, vp]
         _lib.ic_verify_score.argtypes = [vp, ctypes.c_int32, vp, vp, vp]
+        _lib.ic_graph_begin.argtypes = [vp]
+        _lib.ic_graph_end.argtypes = [vp, vp, vp]
+        _lib.ic_graph_launch.argtypes = [vp, vp]
+        _lib.ic_graph_destroy.argtypes = [vp]
     return _lib
 
 
@@ -152,7 +156,12 @@ def stream_handle():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
+PROF_ON = False  # (mirrors the library's flag: launch sequences are not captured in graphs while it is set)
+
+
 def prof_enable(on: bool) -> None:
+    global PROF_ON
+    PROF_ON = bool(on)
     lib().ic_prof_enable(ctypes.c_int(1 if on else 0))
 
 

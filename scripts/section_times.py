@@ -24,6 +24,8 @@ m.engine._drive = timed("engine._drive(loop fwd)", m.engine._drive)
 m.engine.backward = timed("engine.backward(loop bwd)", m.engine.backward)
 m.engine.run = timed("engine.run(total)", m.engine.run)
 m.engine.run_lockstep = timed("engine.run_lockstep(multi-stream fwd)", m.engine.run_lockstep)
+m.engine.run_steered = timed("engine.run_steered(device-steered strict loops)", m.engine.run_steered)
+m.engine.resolve_steered = timed("engine.resolve_steered", m.engine.resolve_steered)
 if len(sys.argv) > 2:
     m.stream_mode = sys.argv[2]  # strict | multi
 T.make_negatives = timed("make_negatives", T.make_negatives)

@@ -80,6 +80,24 @@ def test_steered_train_steps_equal_host_steered(name):
             assert torch.equal(x, y)
 
 
+def test_steered_loops_replay_one_captured_graph():
+    """Three steps of the bench model: the launch sequence of the loops is captured once (HIP graph) and replayed;
+    same results as launching call by call."""
+    from ironcortex_amd import engine as E
+    a, ca, la, _ = run_steps("bench10m", True, n_steps=3)
+    assert ca.get("steered", 0) == 3 and ca.get("graph_captures", 0) == 1, ca
+    old = E.GRAPH
+    E.GRAPH = False
+    try:
+        b, cb, lb, _ = run_steps("bench10m", True, n_steps=3)
+    finally:
+        E.GRAPH = old
+    assert cb.get("steered", 0) == 3 and cb.get("graph_captures", 0) == 0, cb
+    assert_same(a, b)
+    for x, y in zip(la[:3], lb[:3]):
+        assert torch.equal(x, y)
+
+
 def test_steered_loops_that_halt_early():
     """Sharpened token heads drive the uncertainty below 0.05: every loop halts after iteration K_inner // 2 and the
     launches queued behind it must pass the state through untouched."""
