@@ -568,7 +568,7 @@ typedef struct ic_linear_bwd_args {
   float* gx;               /* [B,n] or NULL */
   float* gW;               /* [rows,n] or NULL */
   float* gb;               /* [rows] or NULL */
-  float* slab;             /* [ceil(rows/32),B,n] workspace, needed when gx != NULL and rows > 32 */
+  float* slab;             /* [B,rows] workspace (gz), needed when gx != NULL; rows <= 2048 then */
 } ic_linear_bwd_args;
 int ic_linear_bwd(const ic_linear_bwd_args* a, ic_stream_t stream);
 

@@ -596,14 +596,19 @@ class LinearActFn(torch.autograd.Function):
         gx = torch.empty_like(x) if need_x else None
         gW = torch.empty_like(W) if need_W else None
         gb = torch.empty_like(b) if need_b else None
-        nblk = (rows + 31) // 32
-        slab = torch.empty(nblk, B, n, device=x.device) if need_x and nblk > 1 else None
+        slab = torch.empty(B, rows, device=x.device) if need_x else None
         a = new("ic_linear_bwd_args", B=B, n=n, rows=rows, act=ctx.act, W=W, b=b, x=x, gy=gy.contiguous(), gx=gx, gW=gW, gb=gb, slab=slab)
         _call("ic_linear_bwd", a)
         return gx, gW, gb, None
 
 
+LINEAR_MAX_OUT = 2048  # output rows ic_linear_bwd's input-gradient kernel stages per workgroup
+
+
 def linear_act(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act: str = "none") -> torch.Tensor:
+    if W.shape[0] > LINEAR_MAX_OUT:  # wider than any head of the model: plain PyTorch
+        y = torch.nn.functional.linear(x, W, b)
+        return torch.nn.functional.gelu(y) if act == "gelu" else (torch.nn.functional.silu(y) if act == "silu" else y)
     return LinearActFn.apply(x, W, b, ACTS[act])
 
 
