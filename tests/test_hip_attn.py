@@ -155,7 +155,9 @@ def test_heads_wider_than_the_kernels_keep_the_torch_formulation():
 
 # ---------------------------------------------------------------- fused linear layers of the loss heads (ic_linear_bwd)
 @pytest.mark.parametrize("B,n,rows,act", [(8, 256, 256, "gelu"), (16, 515, 256, "silu"), (8, 512, 1, "none"),
-                                           (3, 256, 2, "none"), (1, 40, 33, "gelu"), (16, 512, 512, "gelu")])
+                                           (3, 256, 2, "none"), (1, 40, 33, "gelu"), (16, 512, 512, "gelu"),
+                                           (2, 64, 64, "silu"), (2, 32, 2, "none"), (2, 64, 1, "none"), (5, 96, 35, "gelu"),
+                                           (16, 1024, 64, "silu"), (6, 30, 70, "gelu")])
 def test_linear_act_forward_backward_vs_torch(B, n, rows, act):
     """y = act(x W^T + b) on the library (forward ic_gemv_chain, backward ic_linear_bwd) against F.linear + the
     activation under torch autograd: outputs and all three gradients, 1e-5 of the largest magnitude; twice the same bits."""

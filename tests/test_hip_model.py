@@ -104,7 +104,11 @@ def test_two_train_steps_vs_reference(name, engine):
         # rounding noise; Adam turns its SIGN into a +-lr step, so such parameters are not comparable
         if ("gnorm." + n) in gold.files and float(gold["gnorm." + n]) < 1e-6:
             continue
-        PL.check(tag, f"pnorm:{n}", float(p.detach().norm()), float(gold["pnorm." + n]), TOL_PNORM, floor=1e-6)
+        # c_attn.bias = [q | k | v] biases: the KEY third has an analytically zero gradient (softmax is invariant to a
+        # shift of all scores of a query), so its Adam steps are ratios of pure rounding noise (|step| anywhere in
+        # [0, lr]); the norm of the whole vector is compared, with an absolute floor that covers that third
+        floor = 1e-5 if n.endswith("c_attn.bias") else 1e-6
+        PL.check(tag, f"pnorm:{n}", float(p.detach().norm()), float(gold["pnorm." + n]), TOL_PNORM, floor=floor)
     PL.flush(tag)
 
 
@@ -283,6 +287,7 @@ def test_early_halt_engine_equals_general_path(monkeypatch):
     halt = lambda scores, u_mean, k, K_inner: k >= 1
     monkeypatch.setattr(E, "should_halt", halt)
     monkeypatch.setattr(M, "should_halt", halt)
+    monkeypatch.setattr(E, "STEER", False)  # a patched halting rule only exists on the host (device-steered halting: test_hip_steer.py)
     gold, cfg, sd, tokens, focus = load_case("allflags")
     outs = []
     for engine in (True, False):
@@ -322,6 +327,7 @@ def test_deferred_winner_equals_immediate(name, monkeypatch):
     from ironcortex_amd import engine as E
     gold, cfg, sd, tokens, focus = load_case(name)
     res = []
+    monkeypatch.setattr(E, "STEER", False)  # (the host-steered loops: device-steered ones never wait at all)
     for defer in (True, False):
         monkeypatch.setattr(E, "DEFER_SYNC", defer)
         model = build(cfg, sd)
@@ -429,7 +435,10 @@ def test_corner_configs_two_train_steps_equal_oracle(kw, T):
     tag = "train/corner/" + "_".join(f"{k}{v}" for k, v in kw.items() if k in ("R", "k_active", "B_br")) + f"_T{T}"
     for step, (o, h) in enumerate(zip(*runs)):
         for k in KEYS:
-            PL.check(tag, f"metric:{step}.{k}", h[k], float(o[k]), 1e-4, floor=1e-4)
+            # step 1 runs on parameters that AdamW moved by lr * g / sqrt(v): for a parameter whose step-0 gradient is
+            # small, the fp32 summation order of that gradient decides the step (observed after the round-3 change of
+            # ic_linear_bwd's input-gradient order: 1.1e-4 absolute on E_neg of the no_kwta corner, 1e-5 before)
+            PL.check(tag, f"metric:{step}.{k}", h[k], float(o[k]), 1e-4, floor=1e-4 if step == 0 else 2.5e-4)
     PL.flush(tag)
 
 
