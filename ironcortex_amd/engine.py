@@ -215,6 +215,7 @@ class LoopEngine:
         """Start of a new forward/backward pass: every step slot may be reused.  The bank's state
         tensors are views of the last loop's final slot until now; copy them out first."""
         self.resolve_pending()
+        self.resolve_open()
         self._rescue_state()
         self.flush_units()
         self._sess = None
@@ -223,6 +224,13 @@ class LoopEngine:
         self._hs_ok = set()  # parameters may have moved since: _heads_setup checks every pointer again
         if self._arena is not None:
             self._arena.reset()
+
+    def resolve_open(self) -> None:
+        """Host-side bookkeeping of the last device-steered batch, if nobody asked for it yet (its backward pass runs
+        from the device-side record): read here, when the step that ran it has long been waited for."""
+        bt, self._steered_open = getattr(self, "_steered_open", None), None
+        if bt is not None:
+            self.resolve_steered(bt)
 
     def new_step(self) -> None:
         """train_step's first call.  A backward pass that raised (OOM, an ic_* error code, a user
@@ -644,6 +652,7 @@ class LoopEngine:
         """Add the logged loops' region steps / active edges / destination regions to the model's
         counters: one batch of ops per arena chunk instead of one per loop."""
         m = self.model
+        self.resolve_open()
         log, self._unit_log = self._unit_log, []
         if m._units is None or not log:
             return
@@ -1317,6 +1326,7 @@ class LoopEngine:
         bt["steered"] = dict(sb=sb, K=K, C=C, Z=Z, flags=flags, kwta_k=kw_k, kwta_temp=kw_temp, keep=(sb["fo"], tables, rP, bP),
                              ebias_grad=bool(ebias.requires_grad), norm_in_w=m.norm_in.weight, denom=denom)
         traces = [SteeredTraces(self, bt, j) for j in range(N)]
+        self._steered_open = bt
         if not grad:  # nothing may refer to the arena afterwards: the traces are copies
             traces = [[t.clone() for t in tr] for tr in traces]
             self._batch = None
@@ -1741,6 +1751,16 @@ class LoopEngine:
         return H_out, masks, logits, traces
 
     # ------------------------------------------------------------------ backward
+    @staticmethod
+    def _steered_stub(sp) -> "_Sample":
+        """What the batched backward and the per-pass reductions read from a loop's host-side record that does not
+        depend on the loop's results (device-steered batches, before their record is read back)."""
+        s = _Sample()
+        s.flags, s.kwta_k, s.kwta_temp = sp["flags"], sp["kwta_k"], sp["kwta_temp"]
+        s.keep, s.ebias_grad, s.norm_in_w, s.ebias = sp["keep"], sp["ebias_grad"], sp["norm_in_w"], sp["sb"]["ebias"]
+        s.zero_in, s.ts = True, 1
+        return s
+
     def backward(self, s: _Sample, gH_final: torch.Tensor):
         m = self.model
         bank, router = m.bank, m.router
@@ -1980,6 +2000,8 @@ class LoopEngine:
     def _batch_uniform(self, bt) -> bool:
         """True when the recorded loops sit n_max slots apart in one chunk, started from the shared
         all-zero input state, and share parameters, flags and schedule."""
+        if bt.get("steered") is not None:
+            return True  # device-steered loops (run_steered) are laid out that way by construction
         ss = bt["samples"]
         s0, K = ss[0], bt["n_max"]
         for j, s in enumerate(ss):
@@ -2026,10 +2048,15 @@ class LoopEngine:
         dev = gH_all.device
         R, d, E = m.R, m.d, router.E
         Ez = max(E, 1)
-        ss = bt["samples"]
-        S, K = len(ss), bt["n_max"]
+        sp = bt.get("steered")  # device-steered loops whose record (winners, parents) is still on the device:
+        if sp is not None:      # everything below that depends on it stays a device tensor -- no host wait
+            ss, S, K = None, bt["n_loops"], bt["n_max"]
+            s0 = self._steered_stub(sp)
+        else:
+            ss = bt["samples"]
+            S, K = len(ss), bt["n_max"]
+            s0 = ss[0]
         V = S * K
-        s0 = ss[0]
         lock = bool(bt.get("lockstep"))
         sS, tS = (1, S) if lock else (K, 1)  # slot of (loop s, step t) = base + s * sS + t * tS
         # [S,K,...] <-> rows in slot order
@@ -2064,8 +2091,11 @@ class LoopEngine:
             Z[k] = zall[zoff:zoff + V * sz].view(V, sz)
             zp[k] = Z[k].data_ptr()
             zoff += pad(V * sz)
-        best = torch.tensor([s.best for s in ss], device=dev)
         lanes = torch.arange(S, device=dev)
+        if sp is not None:  # slot of every loop's winner (ic_loop_steer's record) -> step index inside its block
+            best = sp["sb"]["rec"][:, 0].long() - (base + lanes * K)
+        else:
+            best = torch.tensor([s.best for s in ss], device=dev)
         from_v(Z["gH"])[lanes, best] = gH_all.reshape(S, R * d)
 
         # ---- tapes: one slot per (loop, step), laid out like the arena block
@@ -2084,18 +2114,27 @@ class LoopEngine:
             RB = {k: (rtape.buf[k].data_ptr(), rtape.buf[k].stride(0) * rtape.buf[k].element_size())
                   for k in rtape.buf}
             # where each stream's step reads its input states: the parent's slot (relative to base)
-            pars = [list(s.parent) + [-1] * (K - s.n) for s in ss]                           # halted loops: padded
-            par = torch.tensor(pars, dtype=torch.int64, device=dev)                           # [S,K]
-            slot = torch.where((par >= 0) & live, lanes[:, None] * sS + par * tS, torch.full_like(par, -1))
+            if sp is not None:
+                # the control block of every iteration holds the slots its branches started from (the zero-state slot
+                # sits right before the block: relative slot -1 = "no parent", as the host-side record says it)
+                Cb, Kit = sp["C"], sp["K"]
+                i_in = ENUMS["IC_CTL_IN_SLOT"]
+                par_abs = sp["sb"]["ctl"][:S * Kit, i_in:i_in + Cb].long().reshape(S, K)
+                slot = torch.where(live, par_abs - base, torch.full_like(par_abs, -1))
+                r_live = [t >= Cb for t in range(K)]                                          # (iteration 0 starts from the zero state)
+            else:
+                pars = [list(s.parent) + [-1] * (K - s.n) for s in ss]                       # halted loops: padded
+                par = torch.tensor(pars, dtype=torch.int64, device=dev)                       # [S,K]
+                slot = torch.where((par >= 0) & live, lanes[:, None] * sS + par * tS, torch.full_like(par, -1))
+                r_live = [any(p >= 0 for p in col) for col in zip(*pars)]                     # host: per step
             in_slot = slot.t().contiguous().to(torch.int32)                                   # [K,S]
             rtape.visited[rt0:rt0 + V].copy_(to_v((slot >= 0).to(_U8)))
-            r_live = [any(p >= 0 for p in col) for col in zip(*pars)]                         # host: per step
 
         # ---- structs
         tables, rP, bP = s0.keep[1], s0.keep[2], s0.keep[3]
         P = dict(bP)
         P["norm_in_w"] = s0.norm_in_w
-        sens = torch.stack([s.sensor.reshape(-1) for s in ss]).contiguous()  # [S,d]
+        sens = sp["sb"]["sens"] if sp is not None else torch.stack([s.sensor.reshape(-1) for s in ss]).contiguous()  # [S,d]
         b = new("ic_region_bwd_args")
         b.f = ops._region_args(bank.spec, P, S, 0.0, s0.kwta_k, flags, s0.kwta_temp)
         b.f.sensor = sens.data_ptr()
@@ -2156,8 +2195,11 @@ class LoopEngine:
             rb_ref = ctypes.byref(rb)
 
         side, have = "a", False
-        step_pos = max((s.step_pos for s in ss), key=len)
-        for t in range(max(s.best for s in ss), -1, -1):  # steps after every loop's winner reach no loss
+        if sp is not None:  # every step slot is replayed: the ones after a loop's winner are masked out (all inactive)
+            step_pos, t_last = [float(t // sp["C"]) / sp["denom"] for t in range(K)], K - 1
+        else:
+            step_pos, t_last = max((s.step_pos for s in ss), key=len), max(s.best for s in ss)
+        for t in range(t_last, -1, -1):  # steps after every loop's winner reach no loss
             bimg.load(b_rows[t])
             b.f.step_pos = step_pos[t]
             other = "b" if side == "a" else "a"
@@ -2300,11 +2342,13 @@ class LoopBatchFn(torch.autograd.Function):
     def backward(ctx, gH):
         eng, bt = ctx.engine, ctx.bt
         gH = gH.contiguous()
-        eng.resolve_steered(bt)  # (device-steered loops: their record is read here, once)
+        if eng.model._units is not None:
+            eng.resolve_steered(bt)  # (bench.py's unit counters want the loops' record on the host)
         if bt.get("lockstep") or eng._batch_uniform(bt):
             eng.counters["batch_bwd"] += 1
             g = eng.backward_batch(bt, gH)
         else:
+            eng.resolve_steered(bt)
             eng.counters["loop_bwd"] += len(bt["samples"])
             g = torch.stack([eng.backward(s, gH[j]) for j, s in enumerate(bt["samples"])])
         return g.view(ctx.sshape), None, None, None

@@ -232,6 +232,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     vals = torch.stack([t.detach().float().reshape(()) for t in (
         ff_loss, rtd_loss, denoise_loss, critic_loss, verifier_loss, E_pos.mean(), E_neg.mean(), rtd_acc,
         denoise_acc, grad_norm, active_frac, ce_loss, total)]).tolist()  # one host sync for all metrics
+    model.engine.resolve_open()  # (device-steered loops: their host-side record, now that the step has been waited for)
     keys = ("ff", "rtd", "denoise", "critic", "verify", "E_pos", "E_neg", "rtd_acc", "denoise_acc", "grad_norm",
             "active_frac", "ce_last", "total")
     out = dict(zip(keys, vals))
