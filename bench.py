@@ -32,7 +32,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROF_STRIDE = 32       # the dominant kernel's launches are event-bracketed 1 in 32 in the timed region (1 in 4 cost ~2.5 ms of a 24 ms step with k_gemv dominant: 500 launches per step)
+PROF_STRIDE = 8        # the dominant kernel's launches are event-bracketed 1 in 8 in the measurement pass after the timed region
+EVENT_STEPS = 3        # steps of that pass
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -107,9 +108,9 @@ def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
 
 def pmc_traffic(kernel: str, cfg_name: str):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r02_pmc_traffic.json; PMC collection serialises kernels, so it is a
+    command (profiles/r03_pmc_traffic.json; PMC collection serialises kernels, so it is a
     separate run, never the timed one).  None when no measurement is on file for the config."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if cfg_name != "10m" or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -218,30 +219,47 @@ def main():
             survey = hip.prof_read()
             survey_bytes = hip.prof_bytes_read()
             hip.prof_enable(False)
-    model.count_units(True)
     dominant = None
-    if timing:
+    if timing and survey:
         # the dominant kernel = the largest summed duration among ALL library kernels (every one has a byte model:
         # algorithmic_bytes() or the library's own launch-time count)
-        if survey:
-            dominant = max(survey, key=lambda k: survey[k][1])
-        # timed region: only the dominant kernel carries events (two event records per launch would
-        # otherwise cost more than most of these kernels run and distort `value`)
-        hip.prof_select(dominant or "", stride=PROF_STRIDE)
-        hip.prof_enable(True)
-        hip.prof_read()
-        hip.prof_bytes_read()
+        dominant = max(survey, key=lambda k: survey[k][1])
+    # timed region: the product path as it ships -- no event bracketing, no unit counters (the reasoning loops of a
+    # step are replayed as ONE captured HIP graph, whose kernels cannot be bracketed individually)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         metrics = ic.train_step(model, opt, tokens, lw, dev, dp=dp)
     sync_all()
     elapsed = time.perf_counter() - t0
-    prof = hip.prof_read() if timing else {}
-    lib_bytes = hip.prof_bytes_read() if timing else {}
-    hip.prof_enable(False)
-    hip.prof_select("")
+    # measurement pass, right after the timed region, same process, same workload: EVENT_STEPS more steps with the
+    # dominant kernel bracketed by HIP events (1 launch in PROF_STRIDE, launched call by call) and the device-side
+    # unit counters on -> roofline.achieved and the per-step unit rates
+    prof, lib_bytes = {}, {}
+    model.count_units(True)
+    if timing:
+        hip.prof_select(dominant or "", stride=PROF_STRIDE)
+        hip.prof_enable(True)
+        hip.prof_read()
+        hip.prof_bytes_read()
+    sync_all()
+    inner0 = model.counters["inner_steps"]
+    t1 = time.perf_counter()
+    for _ in range(EVENT_STEPS):
+        ic.train_step(model, opt, tokens, lw, dev, dp=dp)
+    sync_all()
+    elapsed_units = time.perf_counter() - t1
+    if timing:
+        prof = hip.prof_read()
+        lib_bytes = hip.prof_bytes_read()
+        hip.prof_enable(False)
+        hip.prof_select("")
     units = model.read_units()
+    units["inner_steps"] -= inner0
+    model.count_units(False)
+    unit_scale = args.steps / EVENT_STEPS  # unit counts of EVENT_STEPS steps -> per timed region
+    for k_ in ("region_steps", "inner_steps"):
+        units[k_ + "_timed"] = units[k_] * unit_scale
     if dp is not None:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -283,8 +301,9 @@ def main():
             "config": {"workload": WORKLOAD[args.config], "per_gpu_batch": B, "global_batch": B * world,
                        "seq_len": T, "params": n_params, "mode": "strict-sequential (reference schedule)",
                        "parallelism": f"dp{world}"},
-            "region_steps_per_s": units["region_steps"] / elapsed * world,
-            "inner_steps_per_s": units["inner_steps"] / elapsed * world,
+            # (units counted over the EVENT_STEPS steps after the timed region: same tokens, same schedule)
+            "region_steps_per_s": units["region_steps_timed"] / elapsed * world,
+            "inner_steps_per_s": units["inner_steps_timed"] / elapsed * world,
             "loss_total": metrics["total"],
         }
         roof = None
@@ -322,7 +341,10 @@ def main():
             lib_ms = sum(ms_ for _, ms_ in survey.values())
             roof = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant, args.config), "launches": launches,
-                    "launch_sampling": f"HIP events on 1 launch in {PROF_STRIDE} over the timed region",
+                    "launch_sampling": f"HIP events on 1 launch in {PROF_STRIDE} over {EVENT_STEPS} further steps of the same workload "
+                                       "right after the timed region (which replays the loops as one captured HIP graph: its "
+                                       "kernels cannot be bracketed one by one; rocprofv3 --kernel-trace of this command, "
+                                       "profiles/, times them inside the graph)",
                     "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ab,
                     "dominant_by": "largest summed duration among ALL library kernels in the survey step",
                     "units_per_launch": {k: round(v, 3) for k, v in (bwd if dominant.endswith("_bwd") else fwd).items()

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 ( while true; do sleep 45; echo "[profile_round] alive $(date +%T)"; done ) &
 HB=$!
 trap "kill $HB 2>/dev/null" EXIT
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-kernel-sweep --no-multi-stream"
+ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-kernel-sweep --no-multi-stream"  # (+ 3 unit-counting steps after the timed ones: 9 train_steps in the trace)
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 $R/bench.py $ARGS > $OUT/prof_ks.log 2>&1 || { echo "kernel-trace pass failed"; exit 1; }
 cp $(find /tmp/prof_ks -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 PARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-kernel-sweep --no-multi-stream"
