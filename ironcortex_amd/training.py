@@ -210,16 +210,20 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         # Hebbian nudges on edges whose two ends were active in a positive sample (training.py:147-156,240-243)
         if gains is not None and model.router.E > 0:
             router = model.router
+            t = router._edge_tables(model.reg_coords)
+            Hh = H_pos.detach()
+            mp = mask_p.to(H_pos.dtype)
+            if dp is not None:  # every rank applies the whole global batch's nudges
+                Hh, mp = dp.gather(Hh), dp.gather(mp)
+            coef = (1e-3 * gains.clamp_min(0.0))[router.dst_idx].unsqueeze(0) * mp[:, router.dst_idx] * mp[:, router.src_idx]
             if router.edge_transform_mode != "per_edge":
-                if bool((gains > 0).any()):
-                    raise AttributeError("Router has no W_edge in this edge_transform_mode (reference training.py:242)")
+                # the reference indexes router.W_edge here, which only per_edge mode defines (gate.py:136-137): it raises
+                # as soon as ONE update is due (positive gain, region and a neighbour active in a positive sample) --
+                # after the backward and the gain / tau updates, before homeostasis and the optimizer step.  Mirrored.
+                if bool(((gains > 0)[router.dst_idx].unsqueeze(0) & (mp[:, router.dst_idx] > 0) & (mp[:, router.src_idx] > 0)).any()):
+                    raise AttributeError("'Router' object has no attribute 'W_edge' (edge_transform_mode="
+                                         f"{router.edge_transform_mode!r}; reference training.py:240-243)")
             else:
-                t = router._edge_tables(model.reg_coords)
-                Hh = H_pos.detach()
-                mp = mask_p.to(H_pos.dtype)
-                if dp is not None:  # every rank applies the whole global batch's nudges
-                    Hh, mp = dp.gather(Hh), dp.gather(mp)
-                coef = (1e-3 * gains.clamp_min(0.0))[router.dst_idx].unsqueeze(0) * mp[:, router.dst_idx] * mp[:, router.src_idx]
                 ops.hebbian_rank1(router._flat.stacked("W"), t["dst_of_edge"], t["src"], t["widx"], coef, Hh)
                 if model._units is not None:  # bench.py's device-side unit counters: edges this launch updates
                     model._units[14:16] += torch.stack([torch.ones((), device=coef.device), (coef != 0).any(0).sum().float()])

@@ -411,6 +411,13 @@ def oracle_train_step(model: OracleReasoner, optimizer, clean_tokens: torch.Tens
         if p.grad is not None:
             gn += float(p.grad.detach().pow(2).sum().item())
     with torch.no_grad():
+        if model.router.mode != "per_edge" and model.router.keys:
+            # training.py:240-243 indexes router.W_edge, which only per_edge mode defines (gate.py:136-137): the
+            # reference raises as soon as ONE update is due (positive gain, region and a neighbour active in a sample)
+            due = any(float(gains[r]) > 0 and bool(mask_p[b, r]) and bool(mask_p[b, s_])
+                      for r, nb in enumerate(model.neighbors) for s_ in nb for b in range(mask_p.shape[0]))
+            if due:
+                raise AttributeError("'Router' object has no attribute 'W_edge'")
         if model.router.mode == "per_edge" and model.router.keys:
             W = torch.stack([model.router.W_edge[k].weight for k in model.router.keys])
             W2 = O.hebbian_updates(W, model.neighbors, gains, H_pos.detach(), mask_p)

@@ -293,6 +293,41 @@ def corner_fixture():
     model_fixture(CORNER_CASES)
 
 
+def shared_fixture():
+    """by_direction / factorized router modes through the whole model."""
+    import random
+    from ironcortex import CortexConfig, CortexReasoner, LossWeights, train_step
+    from tests.model_cases import SHARED_CASES, SHARED_RAISE
+    model_fixture(SHARED_CASES)
+    # forward-forward loss on: the reference's Hebbian block raises (training.py:240-243) -- record when, and what the
+    # step had already changed by then (gain_ema / tau are updated before the backward, homeo and the optimizer after)
+    blob = {}
+    for name, kw in SHARED_RAISE.items():
+        torch.manual_seed(11); random.seed(11)
+        cfg = CortexConfig(**kw)
+        model = CortexReasoner(hex_neighbors(cfg.R), hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
+        for k, v in model.state_dict().items():
+            blob[f"{name}.sd.{k}"] = npy(v)
+        tokens = (gi.det(31, MODEL_B, MODEL_T, kind="rand") * (cfg.V - 1)).long()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        torch.manual_seed(77); random.seed(77)
+        raised_at, err = -1, ""
+        for step in range(3):
+            try:
+                out = train_step(model, opt, tokens, LossWeights(), torch.device("cpu"))
+                for k, v in out.items():
+                    blob[f"{name}.step{step}.{k}"] = np.array(v, dtype=np.float64)
+            except AttributeError as e:
+                raised_at, err = step, type(e).__name__
+                break
+        blob[f"{name}.raised_at"] = np.array(raised_at)
+        blob[f"{name}.gain_ema"] = npy(model.gate.gain_ema)
+        blob[f"{name}.homeo"] = npy(model.gate.homeo)
+        blob[f"{name}.tau"] = npy(torch.stack([f.tau for f in model.reg_ff]))
+        print(name, "raised at step", raised_at, err)
+    save("shared_raise.npz", blob)
+
+
 def model_fixture(cases=None):
     import copy
     import random
@@ -325,7 +360,9 @@ def model_fixture(cases=None):
                         blob["gnorm." + n] = np.array(float(p.grad.norm()))
                         if p.numel() <= 4096 and (n.startswith("regions.0.") or n.startswith("regions.6.") or "W_edge.1->0" in n
                                                   or n.startswith("norm_in") or n.startswith("router.beta") or "query_lin.1." in n
-                                                  or n.startswith("rtdd") or "raw_P_edge.1->0" in n or "key_lin.1->0" in n):
+                                                  or n.startswith("rtdd") or "raw_P_edge.1->0" in n or "key_lin.1->0" in n
+                                                  or n.startswith(("router.W_dir", "router.U.", "router.V.", "router.key_lin_dir",
+                                                                   "router.raw_P_dir")) or "w_edge.1->0" in n):
                             blob["grad." + n] = npy(p.grad)
                 blob["grad_names"] = np.array(names)
         blob["final.gain_ema"] = npy(model.gate.gain_ema); blob["final.homeo"] = npy(model.gate.homeo)

@@ -29,6 +29,27 @@ CORNER_CASES = {
                           enable_adaptive_filter_dynamics=True, enable_ff_energy_alignment=True, surprise_lambda=0.1,
                           surprise_lambda_schedule=4, init_decay=0.5),
 }
+# the shared-matrix router modes (reference gate.py:142-159,274-281), same fixture layout.  The reference's Hebbian
+# block indexes router.W_edge, which only per_edge mode defines (training.py:240-243): with the forward-forward loss on,
+# train_step raises AttributeError as soon as a positive-gain region and an active neighbour meet (SHARED_RAISE below),
+# so the two-step fixtures of these modes run with enable_forward_forward=False.
+SHARED_CASES = {
+    "bydir": dict(R=10, d=32, V=32, K_inner=3, B_br=2, k_active=5, max_T=64, edge_transform_mode="by_direction",
+                  enable_forward_forward=False),
+    "bydir_prec": dict(R=10, d=32, V=32, K_inner=3, B_br=2, k_active=5, max_T=64, edge_transform_mode="by_direction",
+                       enable_precision_routed_messages=True, enable_adaptive_filter_dynamics=True,
+                       enable_forward_forward=False),
+    "factorized": dict(R=10, d=32, V=32, K_inner=3, B_br=2, k_active=5, max_T=64, edge_transform_mode="factorized",
+                       enable_forward_forward=False),
+    "factorized_prec": dict(R=7, d=32, V=32, K_inner=3, B_br=2, k_active=4, max_T=64, edge_transform_mode="factorized",
+                            enable_precision_routed_messages=True, enable_radial_tangential_updates=True,
+                            enable_forward_forward=False),
+}
+# forward-forward loss ON in a shared-matrix mode: what the reference's train_step does (fixture shared_raise.npz)
+SHARED_RAISE = {
+    "bydir_ff": dict(R=10, d=32, V=32, K_inner=3, B_br=2, k_active=5, max_T=64, edge_transform_mode="by_direction"),
+    "factorized_ff": dict(R=10, d=32, V=32, K_inner=3, B_br=2, k_active=5, max_T=64, edge_transform_mode="factorized"),
+}
 MODEL_B, MODEL_T = 2, 24
 
 # Full-size cases: the exact bench model (reference train_tiny_shakespeare_10m.py:32-48)
@@ -71,7 +92,7 @@ def load_case(name):
                 sd[k] = gi.synth_tensor(int(spec[0]), [int(x) for x in spec[3:]], float(spec[1]), float(spec[2]))
         tokens, focus = big_inputs(name)
         return gold, cfg, sd, tokens, focus
-    cfg = CortexConfig(**(MODEL_CASES[name] if name in MODEL_CASES else CORNER_CASES[name]))
+    cfg = CortexConfig(**(MODEL_CASES[name] if name in MODEL_CASES else (CORNER_CASES[name] if name in CORNER_CASES else SHARED_CASES[name])))
     sd = {k[3:]: torch.as_tensor(gold[k]) for k in gold.files if k.startswith("sd.")}
     tokens = (gi.det(31, MODEL_B, MODEL_T, kind="rand") * (cfg.V - 1)).long()
     focus = gi.det(32, MODEL_B, MODEL_T, kind="rand") < 0.3

@@ -14,7 +14,7 @@ import torch
 
 from tests import parity_log as PL
 from tests.golden import inputs as gi
-from tests.model_cases import BIG_CASES, CORNER_CASES, MODEL_CASES, grad_probes, load_case, seed_train
+from tests.model_cases import BIG_CASES, CORNER_CASES, MODEL_CASES, SHARED_CASES, grad_probes, load_case, seed_train
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -30,7 +30,7 @@ def build(cfg, sd):
     return model.to(DEV)
 
 
-ALL_CASES = list(MODEL_CASES) + list(CORNER_CASES) + list(BIG_CASES)
+ALL_CASES = list(MODEL_CASES) + list(CORNER_CASES) + list(SHARED_CASES) + list(BIG_CASES)
 # Tolerances (relative to the reference tensor's largest magnitude; see tests/parity_log.py).
 # TOL_* are ~3x the worst error OBSERVED on MI355X over all cases (profiles/r02_parity_errors.jsonl);
 # the north_star asks for "about 1e-5 relative" and every forward quantity meets it.
@@ -440,6 +440,45 @@ def test_corner_configs_two_train_steps_equal_oracle(kw, T):
             # ic_linear_bwd's input-gradient order: 1.1e-4 absolute on E_neg of the no_kwta corner, 1e-5 before)
             PL.check(tag, f"metric:{step}.{k}", h[k], float(o[k]), 1e-4, floor=1e-4 if step == 0 else 2.5e-4)
     PL.flush(tag)
+
+
+@pytest.mark.parametrize("engine", [True, False], ids=["engine", "general"])
+@pytest.mark.parametrize("name", ["bydir_ff", "factorized_ff"])
+def test_shared_modes_raise_where_the_reference_does(name, engine):
+    """Forward-forward loss on with a shared-matrix router: the reference's Hebbian block indexes router.W_edge
+    (training.py:240-243), which these modes do not define -- AttributeError at the first step with an update due
+    (step 1 in the reference's recorded run, tests/golden/shared_raise.npz), after that step's gain / tau updates,
+    before homeostasis and the optimizer."""
+    import random
+    import ironcortex_amd as ic
+    from ironcortex_amd.config import CortexConfig
+    from tests.model_cases import GOLD, MODEL_B, MODEL_T, SHARED_RAISE
+    gold = np.load(os.path.join(GOLD, "shared_raise.npz"))
+    cfg = CortexConfig(**SHARED_RAISE[name])
+    sd = {k[len(name) + 4:]: torch.as_tensor(gold[k]) for k in gold.files if k.startswith(name + ".sd.")}
+    model = build(cfg, sd)
+    model.engine.enabled = engine
+    tokens = (gi.det(31, MODEL_B, MODEL_T, kind="rand") * (cfg.V - 1)).long().to(DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    seed_train()
+    raised_at = -1
+    tag = f"train/{name}/{'engine' if engine else 'general'}"
+    for step in range(3):
+        try:
+            out = ic.train_step(model, opt, tokens, ic.LossWeights(), torch.device(DEV))
+        except AttributeError:
+            raised_at = step
+            break
+        for k in KEYS:
+            PL.check(tag, f"metric:{step}.{k}", out[k], float(gold[f"{name}.step{step}.{k}"]), TOL_METRIC, floor=1e-6)
+    assert raised_at == int(gold[name + ".raised_at"]) == 1
+    PL.check(tag, "gain_ema", model.gate.gain_ema, gold[name + ".gain_ema"], TOL_BUF)
+    PL.check(tag, "homeo", model.gate.homeo, gold[name + ".homeo"], TOL_BUF)
+    PL.check(tag, "tau", torch.stack([f.tau for f in model.reg_ff]), gold[name + ".tau"], TOL_BUF)
+    PL.flush(tag)
+    # the failed step must not poison the next one (the coordinator / tapes are reset by train_step)
+    with pytest.raises(AttributeError):
+        ic.train_step(model, opt, tokens, ic.LossWeights(), torch.device(DEV))
 
 
 def test_three_branches_raise_as_in_the_reference():

@@ -7,13 +7,14 @@ import pytest
 import torch
 
 from oracle import model as OM
-from tests.model_cases import BIG_CASES, CORNER_CASES, MODEL_CASES, grad_probes, load_case, seed_train
+from tests.golden import inputs as gi
+from tests.model_cases import BIG_CASES, CORNER_CASES, MODEL_CASES, SHARED_CASES, grad_probes, load_case, seed_train
 
 KEYS = ("ff", "rtd", "denoise", "critic", "verify", "E_pos", "E_neg", "E_gap", "rtd_acc", "denoise_acc",
         "grad_norm", "active_frac", "lambda_s", "ce_last", "total")
 
 
-@pytest.mark.parametrize("name", list(MODEL_CASES) + list(CORNER_CASES) + list(BIG_CASES))
+@pytest.mark.parametrize("name", list(MODEL_CASES) + list(CORNER_CASES) + list(SHARED_CASES) + list(BIG_CASES))
 def test_state_dict_keys_and_loop(name):
     gold, cfg, sd, tokens, focus = load_case(name)
     model = OM.build(cfg)
@@ -31,7 +32,7 @@ def test_state_dict_keys_and_loop(name):
     torch.testing.assert_close(en, torch.as_tensor(gold["loop.energy"]), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", list(MODEL_CASES) + list(CORNER_CASES) + list(BIG_CASES))
+@pytest.mark.parametrize("name", list(MODEL_CASES) + list(CORNER_CASES) + list(SHARED_CASES) + list(BIG_CASES))
 def test_two_train_steps(name):
     gold, cfg, sd, tokens, focus = load_case(name)
     model = OM.build(cfg)
@@ -82,3 +83,35 @@ def test_evaluate_perplexity(name):
     assert out["perplexity"] == pytest.approx(float(ev[name + ".perplexity"]), rel=1e-6)
     num = torch.stack([c.st["num"] for c in model.regions])
     torch.testing.assert_close(num, torch.as_tensor(ev[name + ".num"]), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["bydir_ff", "factorized_ff"])
+def test_shared_modes_raise_where_the_reference_does(name):
+    """Forward-forward loss on with a shared-matrix router: the reference's Hebbian block indexes router.W_edge
+    (training.py:240-243), which these modes do not define -- AttributeError at the first step with an update due
+    (step 1 here), after that step's gain / tau updates.  tests/golden/shared_raise.npz is the reference's run."""
+    import os
+    import random
+    from oracle import model as OM
+    from ironcortex_amd.config import CortexConfig
+    from tests.model_cases import GOLD, MODEL_B, MODEL_T, SHARED_RAISE
+    gold = np.load(os.path.join(GOLD, "shared_raise.npz"))
+    cfg = CortexConfig(**SHARED_RAISE[name])
+    om = OM.build(cfg)
+    om.load_state_dict({k[len(name) + 4:]: torch.as_tensor(gold[k]) for k in gold.files if k.startswith(name + ".sd.")})
+    tokens = (gi.det(31, MODEL_B, MODEL_T, kind="rand") * (cfg.V - 1)).long()
+    opt = torch.optim.AdamW(om.parameters(), lr=1e-3)
+    torch.manual_seed(77); random.seed(77)
+    raised_at = -1
+    for step in range(3):
+        try:
+            out = OM.oracle_train_step(om, opt, tokens, OM.LossWeights())
+        except AttributeError:
+            raised_at = step
+            break
+        for k, v in out.items():
+            assert v == pytest.approx(float(gold[f"{name}.step{step}.{k}"]), rel=2e-5, abs=2e-6), (step, k)
+    assert raised_at == int(gold[name + ".raised_at"]) == 1
+    torch.testing.assert_close(om.gate.gain_ema, torch.as_tensor(gold[name + ".gain_ema"]), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(om.gate.homeo, torch.as_tensor(gold[name + ".homeo"]), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(torch.stack([f.tau for f in om.reg_ff]), torch.as_tensor(gold[name + ".tau"]), rtol=1e-5, atol=1e-7)
