@@ -55,10 +55,16 @@ enum {
 /* router flags */
 enum {
   IC_RF_PRECISION = 1 << 0, /* enable_precision_routed_messages (gate.py:292-318) */
-  IC_RF_SHARED = 1 << 1     /* widx selects one of nW <= 8 matrices SHARED by many edges (edge_transform_mode
+  IC_RF_SHARED = 1 << 1,    /* widx selects one of nW <= 8 matrices SHARED by many edges (edge_transform_mode
                                "by_direction", gate.py:142-149,274-277) and no destination has two incoming edges
                                with the same widx: without IC_RF_PRECISION the forward then runs as ONE GEMM
                                [d, nW*d] x [nW*d, S*R] on the matrix cores (fp32 MFMA) instead of per-edge GEMVs */
+  IC_RF_FACTORIZED = 1 << 2 /* edge_transform_mode "factorized" (gate.py:150-159,278-281): msg_e = ebias_e * U (w_e * V h_src)
+                               with two matrices shared by ALL edges.  Without precision routing the messages of a
+                               destination are summed, so M[dst] = U (sum_e ebias_e * w_e * (V h_src_e)): V once per
+                               active sender and U once per destination with an active in-edge, both as shared-matrix
+                               GEMMs over the (stream, region) columns (fp32 MFMA forward), an elementwise mix in
+                               between.  Not combined with IC_RF_PRECISION.  See the fact_* fields. */
 };
 
 const char* ic_last_error(void);
@@ -216,6 +222,16 @@ typedef struct ic_router_args {
                            block in_slot[s] of H / mask_prev (R*d floats / R bytes per block; the strides above are
                            ignored): the streams of a multi-stream launch (independent reasoning loops run in
                            lockstep) each continue from their own winner of the previous outer iteration. */
+  /* IC_RF_FACTORIZED only (W, key_W, query_W, raw_P unused): */
+  const float* fact_U;      /* [d,d]  Router.U.weight */
+  const float* fact_V;      /* [d,d]  Router.V.weight */
+  const float* fact_w;      /* [E,d]  Router.w_edge, edge order */
+  const int32_t* fact_iota; /* [R+1]  0, 1, ..., R: identity edge tables of the two row GEMMs */
+  const int32_t* fact_zero; /* [R]    zeros (their widx) */
+  const float* fact_ones;   /* [R]    ones (their edge bias) */
+  float* fact_t;            /* [S,R,d] saved: V h of the active senders, zeros elsewhere */
+  float* fact_z;            /* [S,R,d] saved: sum over the active in-edges of ebias_e * w_e * t[src_e] */
+  uint8_t* fact_dact;       /* [S,R]   saved: 1 if the region has an active in-edge */
 } ic_router_args;
 int ic_router_fwd(const ic_router_args* a, ic_stream_t stream);
 
@@ -245,6 +261,18 @@ typedef struct ic_router_bwd_args {
                          from block in_slot[s] of f.H / f.mask_prev (R*d floats / R bytes per block) and
                          writes gH to block in_slot[s] of gH (the strides above are ignored);
                          in_slot[s] < 0: the stream is skipped (tape_eact / tape_qact rows cleared). */
+  /* IC_RF_FACTORIZED only.  Per-stream arrays follow sk like the others.  tape_gmsg is unused; tape_H (copy of H) and
+   * tape_eact (edge activity, decides which w_e hold a gradient) are written as usual. */
+  float* g_fw_rows;   /* [S,E,d] rows of d/d w_e (written for active edges; host reduces over S and steps) */
+  float* fact_gz;     /* [S,R,d] workspace: U^T gM */
+  float* fact_gt;     /* [S,R,d] workspace: gradient w.r.t. t */
+  float* fact_slab;   /* [nslab,S,R,d] workspace of the two row GEMMs' input gradients */
+  float* fact_gb;     /* [nslab,S,R] workspace (their unused edge-bias partials) */
+  float* tape_gU;     /* [S,R,d] tape slot of dU = sum gM (x) z:  gradient rows */
+  float* tape_zU;     /* [S,R,d]                                   operand rows (copy of fact_z) */
+  uint8_t* tape_aU;   /* [S,R]                                     row took part */
+  float* tape_gV;     /* [S,R,d] tape slot of dV = sum gt (x) H:  gradient rows (operand: tape_H) */
+  uint8_t* tape_aV;   /* [S,R]                                     row took part */
 } ic_router_bwd_args;
 int ic_router_bwd(const ic_router_bwd_args* a, ic_stream_t stream);
 

@@ -899,6 +899,106 @@ __global__ __launch_bounds__(256) void k_hebbian(float* W, const int32_t* dst_of
   }
 }
 
+// ---------------------------------------------------------------- factorized mode (IC_RF_FACTORIZED)
+// msg_e = ebias_e * U (w_e * V h_src)  (gate.py:150-159,278-281); without precision routing the messages of a
+// destination are summed, so M[dst] = U z[dst], z[dst] = sum_e ebias_e * w_e * t[src_e], t = V h: the two matrix
+// products are shared-matrix GEMMs over the (stream, region) columns (router_mfma.hip, identity edge tables), the
+// mix between them and its backward are the two elementwise kernels below.
+template <int DCH>
+__global__ __launch_bounds__(256) void k_fact_mix_fwd(ic_router_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.S * a.R) return;
+  const int d = a.d, s = row / a.R, r = row % a.R;
+  RowFrag<DCH> acc;
+  zero_frag(acc);
+  bool any = false;
+  for (int e = a.dst_off[r]; e < a.dst_off[r + 1]; ++e) {  // edge order: the reference's index_add_ order
+    const int src = a.src[e];
+    if (!prev_on(a, s, src)) continue;
+    any = true;
+    RowFrag<DCH> t, w;
+    load_row(t, a.fact_t + ((size_t)s * a.R + src) * d, d, lane);
+    load_row(w, a.fact_w + (size_t)e * d, d, lane);
+    const float bias = a.ebias[e];
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      acc.v[j].x += bias * (w.v[j].x * t.v[j].x); acc.v[j].y += bias * (w.v[j].y * t.v[j].y);
+      acc.v[j].z += bias * (w.v[j].z * t.v[j].z); acc.v[j].w += bias * (w.v[j].w * t.v[j].w);
+    }
+  }
+  store_row(acc, a.fact_z + (size_t)row * d, d, lane);
+  if (lane == 0) a.fact_dact[row] = any ? 1 : 0;
+}
+
+__device__ __forceinline__ int dst_of_edge(const ic_router_args& a, int e) {
+  int lo = 0, hi = a.R;  // the r with dst_off[r] <= e < dst_off[r + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.dst_off[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// rows [0, S*E): per (stream, edge) -- d/d w_e rows, d/d ebias_e, edge activity for the tape;
+// rows [S*E, S*E + S*R): per (stream, sender) -- gt = sum over the sender's out-edges of ebias_e * w_e * gz[dst_e]
+template <int DCH>
+__global__ __launch_bounds__(256) void k_fact_mix_bwd(ic_router_bwd_args b) {
+  const ic_router_args& a = b.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int id = blockIdx.x * 4 + wave;
+  const int d = a.d, sk = stream_step(b);
+  const int nE = a.S * a.E, nR = a.S * a.R;
+  if (id < nE) {
+    const int s = id / a.E, e = id % a.E, vs = s * sk;
+    const int src = a.src[e];
+    const bool act = prev_on(b, s, src);  // (false for a skipped stream)
+    if (lane == 0) b.tape_eact[(size_t)vs * a.E + e] = act ? 1 : 0;
+    if (!act) return;
+    const int dst = dst_of_edge(a, e);
+    RowFrag<DCH> gz, t, w, out;
+    load_row(gz, b.fact_gz + ((size_t)vs * a.R + dst) * d, d, lane);
+    load_row(t, a.fact_t + ((size_t)vs * a.R + src) * d, d, lane);
+    load_row(w, a.fact_w + (size_t)e * d, d, lane);
+    const float bias = a.ebias[e];
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < DCH; ++j) {
+      const int c = 4 * lane + 256 * j;
+      out.v[j] = make_float4(bias * (gz.v[j].x * t.v[j].x), bias * (gz.v[j].y * t.v[j].y), bias * (gz.v[j].z * t.v[j].z),
+                             bias * (gz.v[j].w * t.v[j].w));
+      if (c < d)
+        part += (gz.v[j].x * (w.v[j].x * t.v[j].x) + gz.v[j].y * (w.v[j].y * t.v[j].y)) +
+                (gz.v[j].z * (w.v[j].z * t.v[j].z) + gz.v[j].w * (w.v[j].w * t.v[j].w));
+    }
+    store_row(out, b.g_fw_rows + ((size_t)vs * a.E + e) * d, d, lane);
+    part = wave_sum(part);
+    if (lane == 0) b.g_ebias_part[(size_t)vs * a.E + e] = part;  // (slab 0; the other slabs stay zero)
+    return;
+  }
+  const int id2 = id - nE;
+  if (id2 >= nR) return;
+  const int s = id2 / a.R, r = id2 % a.R, vs = s * sk;
+  RowFrag<DCH> acc;
+  zero_frag(acc);
+  if (prev_on(b, s, r)) {
+    for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
+      const int e = b.src_edges[i];
+      const int dst = dst_of_edge(a, e);
+      RowFrag<DCH> gz, w;
+      load_row(gz, b.fact_gz + ((size_t)vs * a.R + dst) * d, d, lane);
+      load_row(w, a.fact_w + (size_t)e * d, d, lane);
+      const float bias = a.ebias[e];
+#pragma unroll
+      for (int j = 0; j < DCH; ++j) {
+        acc.v[j].x += bias * (w.v[j].x * gz.v[j].x); acc.v[j].y += bias * (w.v[j].y * gz.v[j].y);
+        acc.v[j].z += bias * (w.v[j].z * gz.v[j].z); acc.v[j].w += bias * (w.v[j].w * gz.v[j].w);
+      }
+    }
+  }
+  store_row(acc, b.fact_gt + ((size_t)vs * a.R + r) * d, d, lane);
+}
+
 }  // namespace
 
 static int check_router(const ic_router_args* a, const char* who) {
@@ -906,7 +1006,13 @@ static int check_router(const ic_router_args* a, const char* who) {
   IC_REQUIRE(a->S > 0 && a->R > 0 && a->E >= 0, "%s: S=%d R=%d E=%d", who, a->S, a->R, a->E);
   IC_REQUIRE(a->d >= 4 && a->d % 4 == 0 && a->d <= 1024, "%s: d=%d unsupported", who, a->d);
   IC_REQUIRE(a->dst_off && a->H && a->mask_prev && a->M, "%s: NULL pointer", who);
-  IC_REQUIRE(a->E == 0 || (a->src && a->widx && a->W && a->ebias), "%s: NULL edge pointer", who);
+  IC_REQUIRE(a->E == 0 || (a->src && a->widx && (a->W || (a->flags & IC_RF_FACTORIZED)) && a->ebias), "%s: NULL edge pointer", who);
+  if (a->flags & IC_RF_FACTORIZED) {
+    IC_REQUIRE(!(a->flags & IC_RF_PRECISION), "%s: IC_RF_FACTORIZED with IC_RF_PRECISION is not supported", who);
+    IC_REQUIRE(a->E == 0 || (a->fact_U && a->fact_V && a->fact_w && a->fact_iota && a->fact_zero && a->fact_ones && a->fact_t &&
+                             a->fact_z && a->fact_dact),
+               "%s: NULL factorized-mode pointer", who);
+  }
   if (a->flags & IC_RF_PRECISION)
     IC_REQUIRE(a->key_W && a->query_W && a->raw_P && a->msg && a->keyv && a->q && a->wgt,
                "%s: precision-routing buffers are NULL", who);
@@ -924,11 +1030,73 @@ static int edge_nz(int S, int64_t base_wgs) {
   return nz;
 }
 
+// the identity-table router of one of the two row GEMMs of the factorized mode: R self-edges, one shared matrix
+static ic_router_args fact_rows(const ic_router_args* a, const float* W) {
+  ic_router_args p = {};
+  p.S = a->S; p.R = a->R; p.d = a->d; p.E = a->R; p.flags = IC_RF_SHARED; p.nW = 1;
+  p.dst_off = a->fact_iota; p.src = a->fact_iota; p.widx = a->fact_zero;
+  p.W = W; p.ebias = a->fact_ones;
+  return p;
+}
+
+static int router_fact_fwd(const ic_router_args* a, hipStream_t st) {
+  if (a->E == 0) return IC_OK;
+  ic_router_args p = fact_rows(a, a->fact_V);  // t = V h for the active senders
+  p.H = a->H; p.mask_prev = a->mask_prev; p.H_sstride = a->H_sstride; p.mask_sstride = a->mask_sstride; p.in_slot = a->in_slot;
+  p.M = a->fact_t;
+  int rc = ic_router_shared_fwd_launch(&p, st);
+  if (rc) return rc;
+  IC_DISPATCH_DCH(a->d, {
+    IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_fact_mix_fwd<DCH>, dim3(ic_ceil_div(a->S * a->R, 4)), dim3(256), 0, st, *a));
+  });
+  p = fact_rows(a, a->fact_U);  // M = U z for the destinations with an active in-edge
+  p.H = a->fact_z; p.mask_prev = a->fact_dact; p.M = a->M;
+  return ic_router_shared_fwd_launch(&p, st);
+}
+
+extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream);
+
+static int router_fact_bwd(const ic_router_bwd_args* b, hipStream_t st) {
+  const ic_router_args* a = &b->f;
+  IC_REQUIRE(b->g_fw_rows && b->fact_gz && b->fact_gt && b->fact_slab && b->fact_gb && b->tape_gU && b->tape_zU && b->tape_aU &&
+                 b->tape_gV && b->tape_aV,
+             "ic_router_bwd: NULL factorized-mode gradient pointer");
+  if (a->E == 0) return IC_OK;
+  const int64_t sk = b->sk > 1 ? b->sk : 0;
+  ic_router_bwd_args q = {};
+  q.f = fact_rows(a, a->fact_U);  // gz = U^T gM; tape of dU: rows gM, operand z
+  q.f.H = a->fact_z; q.f.mask_prev = a->fact_dact; q.f.M = b->fact_gz;
+  q.f.H_sstride = sk * a->R * a->d; q.f.mask_sstride = sk * a->R;
+  q.src_off = a->fact_iota; q.src_edges = a->fact_iota;
+  q.gM = b->gM; q.gH = b->fact_gz; q.gH_sstride = sk * a->R * a->d;
+  q.g_ebias_part = b->fact_gb; q.slab = b->fact_slab;
+  q.tape_gmsg = b->tape_gU; q.tape_H = b->tape_zU; q.tape_eact = b->tape_aU;
+  q.sk = b->sk;
+  int rc = ic_router_bwd(&q, (ic_stream_t)st);
+  if (rc) return rc;
+  IC_DISPATCH_DCH(a->d, {
+    IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_fact_mix_bwd<DCH>, dim3(ic_ceil_div(a->S * (a->E + a->R), 4)), dim3(256), 0, st, *b));
+  });
+  q.f = fact_rows(a, a->fact_V);  // gH = V^T gt; tape of dV: rows gt, operand H
+  q.f.H = a->H; q.f.mask_prev = a->mask_prev; q.f.M = b->fact_gz;
+  q.f.H_sstride = a->H_sstride; q.f.mask_sstride = a->mask_sstride;
+  q.in_slot = b->in_slot;
+  q.gM = b->fact_gt; q.gH = b->gH; q.gH_sstride = b->gH_sstride;
+  q.tape_gmsg = b->tape_gV; q.tape_H = b->tape_H; q.tape_eact = b->tape_aV;
+  return ic_router_bwd(&q, (ic_stream_t)st);
+}
+
 extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
   int rc = check_router(a, "ic_router_fwd");
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int nsl = ic_ceil_div(a->d, kRowsPerBlock);
+  if (a->flags & IC_RF_FACTORIZED) {
+    int rc2 = router_fact_fwd(a, st);
+    if (rc2) return rc2;
+    IC_LAUNCH_CHECK("ic_router_fwd");
+    return IC_OK;
+  }
   if (a->flags & IC_RF_PRECISION) {
     IC_DISPATCH_DCH(a->d, {
       IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R, edge_nz(a->S, (int64_t)nsl * (a->E + a->R))), dim3(256), 0, st, *a));
@@ -952,7 +1120,7 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
 // routed region kernel that follows on the same stream.
 int ic_front_launch(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream, bool combine) {
   IC_REQUIRE(g != nullptr && a != nullptr, "ic_front_fwd: NULL args");
-  if (g->R > 64 || a->E == 0 || ((a->flags & IC_RF_SHARED) && !(a->flags & IC_RF_PRECISION))) {
+  if (g->R > 64 || a->E == 0 || ((a->flags & IC_RF_SHARED) && !(a->flags & IC_RF_PRECISION)) || (a->flags & IC_RF_FACTORIZED)) {
     // big maps: the gate's scores want the whole chip (ic_gate_fwd); shared matrices: the router is an MFMA GEMM
     IC_REQUIRE(combine, "ic_front_fwd: no fused launch for R=%d, E=%d", g->R, a->E);
     int rc = ic_gate_fwd(g, stream);
@@ -994,6 +1162,13 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
   const ic_router_args* a = &b->f;
   IC_REQUIRE(b->gM && b->gH && b->tape_H && b->tape_eact && b->src_off,
              "ic_router_bwd: NULL gradient pointer");
+  if (a->flags & IC_RF_FACTORIZED) {
+    IC_REQUIRE(a->E == 0 || (b->src_edges && b->g_ebias_part), "ic_router_bwd: NULL edge gradient pointer");
+    int rc2 = router_fact_bwd(b, (hipStream_t)stream);
+    if (rc2) return rc2;
+    IC_LAUNCH_CHECK("ic_router_bwd");
+    return IC_OK;
+  }
   IC_REQUIRE(a->E == 0 || (b->src_edges && b->g_ebias_part && b->tape_gmsg && b->slab),
              "ic_router_bwd: NULL edge gradient pointer");
   if (a->flags & IC_RF_PRECISION)

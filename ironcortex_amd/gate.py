@@ -132,10 +132,11 @@ class Router(FastAttrs, nn.Module):
             # msg_e = U (w_e * V h_src)   (gate.py:150-159,278-281): two SHARED d x d matrices, i.e.
             # plain [E_act,d] x [d,d] GEMMs -- run through rocBLAS (MFMA) from PyTorch, see _route_factorized
             self.U, self.V = mk(), mk()
-            self.w_edge = nn.ParameterDict({k: nn.Parameter(torch.ones(d)) for k in keys})
+            self.w_edge = nn.ParameterDict({k: ArenaParameter(torch.ones(d)) for k in keys})
             self.key_lin = nn.ModuleDict({k: mk() for k in keys})
             self.raw_P_edge = nn.ParameterDict({k: ArenaParameter(torch.zeros(d)) for k in keys})
-            groups = {"key_W": [self.key_lin[k].weight for k in keys], "raw_P": [self.raw_P_edge[k] for k in keys]}
+            groups = {"U": [self.U.weight], "V": [self.V.weight], "w_e": [self.w_edge[k] for k in keys],
+                      "key_W": [self.key_lin[k].weight for k in keys], "raw_P": [self.raw_P_edge[k] for k in keys]}
             self.nW = self.E
         else:
             raise ValueError(f"unknown edge_transform_mode {edge_transform_mode}")
@@ -208,13 +209,22 @@ class Router(FastAttrs, nn.Module):
         self._tables = {"dst_off": i32(dst_off), "src": i32(src), "widx": i32(widx), "src_off": i32(src_off),
                         "src_edges": i32(src_edges), "dst_of_edge": i32(dst),
                         "widx_long": torch.tensor(widx if E else [0], dtype=torch.long, device=dev)}
+        if self.edge_transform_mode == "factorized":  # identity edge tables of the two shared-matrix row GEMMs
+            self._tables.update(iota=i32(list(range(R + 1))), zero=i32([0] * R), ones=torch.ones(R, device=dev))
         self._tables_key = key
         return self._tables
 
     def spec(self) -> ops.RouterSpec:
         """Static description for the C calls (the edge tables must have been built: _edge_tables)."""
         return ops.RouterSpec(self.R, self.d, self.E, self.nW, self.enable_precision_routed_messages,
-                              shared_gemm=bool(getattr(self, "_shared_gemm", False)))
+                              shared_gemm=bool(getattr(self, "_shared_gemm", False)), factorized=self.fact_lib)
+
+    @property
+    def fact_lib(self) -> bool:
+        """Factorized mode on the library (IC_RF_FACTORIZED): without precision routing, where the messages of a
+        destination are summed and U applies once per destination.  With precision routing every edge's message is
+        needed on its own: that combination stays on _route_factorized (general path only)."""
+        return self.edge_transform_mode == "factorized" and not self.enable_precision_routed_messages and self.E > 0
 
     def _edge_bias(self, reg_coords: torch.Tensor) -> torch.Tensor:
         """1 + fb_alpha * b(delta) per edge (gate.py:284-290); trig of the static geometry is cached."""
@@ -253,6 +263,9 @@ class Router(FastAttrs, nn.Module):
 
     def _params(self) -> Dict[str, torch.Tensor]:
         f = self._flat
+        if self.edge_transform_mode == "factorized":
+            return {"U": f.stacked("U"), "V": f.stacked("V"), "w_e": f.stacked("w_e"), "key_W": f.stacked("key_W"),
+                    "raw_P": f.stacked("raw_P"), "query_W": f.stacked("query_W")}
         return {"W": f.stacked("W"), "key_W": f.stacked("key_W"), "raw_P": f.stacked("raw_P"),
                 "query_W": f.stacked("query_W")}
 
@@ -268,6 +281,13 @@ class Router(FastAttrs, nn.Module):
         dev = self._flat.flat.device
         spec = self.spec()
         tables = self._tables
+        if spec.factorized:  # dU, dV (shared-matrix GEMMs over the tapes' rows); w_e: the edges active in a visited slot
+            tuv = torch.zeros(2, dtype=torch.uint8, device=dev)
+            ops.router_fact_wgrad(tape, spec, tables, self._tape_S, self._flat.stacked_grad("U"), self._flat.stacked_grad("V"), tuv)
+            n = tape.pos
+            te = (tape.buf["eact"][:n] * tape.visited[:n].view(n, 1, 1)).amax((0, 1)).to(torch.uint8)
+            tape.reset()
+            return torch.cat([tuv, te])
         tw = torch.zeros(self.nW, dtype=torch.uint8, device=dev)
         ops.router_wgrad(tape, spec, tables, self._tape_S, 0, self._flat.stacked_grad("W"), tw)
         if spec.precision:
@@ -281,6 +301,11 @@ class Router(FastAttrs, nn.Module):
 
     def _publish(self, flags) -> None:
         """Phase 2: .grad views for the touched matrices."""
+        if self.fact_lib:
+            self._flat.publish("U", flags[0:1])
+            self._flat.publish("V", flags[1:2])
+            self._flat.publish("w_e", flags[2:])
+            return
         tw_l = flags[: self.nW]
         if self.enable_precision_routed_messages:
             tk_l, tq_l = flags[self.nW: 2 * self.nW], flags[2 * self.nW:]
@@ -296,6 +321,9 @@ class Router(FastAttrs, nn.Module):
             R, E, d = self.R, max(self.E, 1), self.d
             fields = {"gmsg": (S, E, d), "H": (S, R, d), "eact": (S, E)}
             dtypes = {"eact": torch.uint8}
+            if self.fact_lib:  # rows and operands of dU / dV instead of per-edge message gradients
+                fields = {"gU": (S, R, d), "zU": (S, R, d), "aU": (S, R), "gV": (S, R, d), "aV": (S, R), "H": (S, R, d), "eact": (S, E)}
+                dtypes = {"eact": torch.uint8, "aU": torch.uint8, "aV": torch.uint8}
             if self.enable_precision_routed_messages:
                 fields.update(gkey=(S, E, d), gq=(S, R, d), qact=(S, R))
                 dtypes["qact"] = torch.uint8
@@ -309,7 +337,7 @@ class Router(FastAttrs, nn.Module):
         dev = H.device
         if self._flat.flat.device != dev:
             raise RuntimeError("Router parameters and input are on different devices")
-        if self.edge_transform_mode == "factorized":
+        if self.edge_transform_mode == "factorized" and not self.fact_lib:
             return torch.stack([self._route_factorized(H[s], mask_prev[s].bool(), reg_coords) for s in range(S)])
         tables = self._edge_tables(reg_coords)
         ebias = self._cached_bias(reg_coords)

@@ -352,15 +352,22 @@ def region_wgrad(tape: Tape, S: int, R: int, d: int, gW: torch.Tensor, touched: 
 
 # ============================================================================ router
 class RouterSpec:
-    def __init__(self, R: int, d: int, E: int, nW: int, precision: bool, shared_gemm: bool = False):
+    def __init__(self, R: int, d: int, E: int, nW: int, precision: bool, shared_gemm: bool = False, factorized: bool = False):
         self.R, self.d, self.E, self.nW, self.precision = R, d, E, nW, precision
         self.shared_gemm = shared_gemm  # by_direction on a map where the GEMM formulation applies (IC_RF_SHARED)
+        self.factorized = factorized    # edge_transform_mode "factorized" without precision routing (IC_RF_FACTORIZED)
 
 
 def _router_args(spec: RouterSpec, T: Dict[str, torch.Tensor], P: Dict[str, torch.Tensor], S: int):
     flags = (IC_RF_PRECISION if spec.precision else 0) | (ENUMS["IC_RF_SHARED"] if spec.shared_gemm else 0)
+    if spec.factorized:
+        flags |= ENUMS["IC_RF_FACTORIZED"]
     a = new("ic_router_args", S=S, R=spec.R, d=spec.d, E=spec.E, flags=flags, nW=spec.nW)
     a.dst_off, a.src, a.widx = T["dst_off"].data_ptr(), T["src"].data_ptr(), T["widx"].data_ptr()
+    if spec.factorized:  # msg_e = ebias_e U (w_e * V h): two shared matrices + per-edge scales, identity tables of the row GEMMs
+        a.fact_U, a.fact_V, a.fact_w = P["U"].data_ptr(), P["V"].data_ptr(), P["w_e"].data_ptr()
+        a.fact_iota, a.fact_zero, a.fact_ones = T["iota"].data_ptr(), T["zero"].data_ptr(), T["ones"].data_ptr()
+        return a
     a.W = P["W"].data_ptr()
     if spec.precision:
         a.key_W, a.query_W, a.raw_P = P["key_W"].data_ptr(), P["query_W"].data_ptr(), P["raw_P"].data_ptr()
@@ -383,8 +390,10 @@ class RouterFn(torch.autograd.Function):
         sv = {}
         if spec.precision:
             sv = dict(msg=_e(H, S, E, d), keyv=_e(H, S, E, d), q=_e(H, S, R, d), wgt=_z(H, S, E))
-            for k, t in sv.items():
-                setattr(a, k, ptr(t))
+        elif spec.factorized:
+            sv = dict(fact_t=_e(H, S, R, d), fact_z=_e(H, S, R, d), fact_dact=_e(H, S, R, dtype=torch.uint8))
+        for k, t in sv.items():
+            setattr(a, k, ptr(t))
         if E > 0:
             _call("ic_router_fwd", a)
         else:
@@ -423,6 +432,16 @@ class RouterFn(torch.autograd.Function):
         for k, t in out.items():
             setattr(b, k, ptr(t))
         b.src_off, b.src_edges = box["tables"]["src_off"].data_ptr(), box["tables"]["src_edges"].data_ptr()
+        if spec.factorized:
+            fx = dict(g_fw_rows=_z(H, S, E, d), fact_gz=_e(H, S, R, d), fact_gt=_e(H, S, R, d),
+                      fact_slab=_e(H, nslab, S, R, d), fact_gb=_e(H, nslab, S, R))
+            for k, t in fx.items():
+                setattr(b, k, ptr(t))
+            for k in ("gU", "zU", "aU", "gV", "aV", "H", "eact"):
+                setattr(b, "tape_" + k, tape.slot(k, slot).data_ptr())
+            _call("ic_router_bwd", b)
+            box["grad_sink"]("w_e", fx["g_fw_rows"].sum(0), box["tables"]["widx_long"])
+            return None, out["gH"], out["g_ebias_part"].sum((0, 1)), None
         b.tape_gmsg = tape.slot("gmsg", slot).data_ptr()
         b.tape_H = tape.slot("H", slot).data_ptr()
         b.tape_eact = tape.slot("eact", slot).data_ptr()
@@ -451,6 +470,24 @@ def router_wgrad(tape: Tape, spec: RouterSpec, tables: Dict[str, torch.Tensor], 
         ws = torch.empty(n, dtype=torch.int32, device=gW.device)
         a.pair_ws, a.pair_ws_len = ptr(ws), n
     _call("ic_router_wgrad", a)
+
+
+def router_fact_wgrad(tape: Tape, spec: RouterSpec, tables: Dict[str, torch.Tensor], S: int, gU: torch.Tensor,
+                      gV: torch.Tensor, touched: torch.Tensor) -> None:
+    """Deferred dU = sum gM (x) z and dV = sum gt (x) H of the factorized mode: the shared-matrix weight-gradient GEMM
+    over the (slot, stream, region) rows of the two tapes (identity edge tables).  touched: uint8 [2] (U, V)."""
+    if tape.pos == 0 or spec.E == 0:
+        return
+    R, d = spec.R, spec.d
+    for i, (g, op, act, gW) in enumerate((("gU", "zU", "aU", gU), ("gV", "H", "aV", gV))):
+        a = new("ic_wgrad_edge_args", T=tape.pos, S=S, R=R, d=d, E=R, nW=1, which=0, dst_off=tables["iota"], src=tables["iota"],
+                widx=tables["zero"], tape_g=tape.buf[g], tape_H=tape.buf[op], tape_eact=tape.buf[act], visited=tape.visited,
+                gW=gW, touched=touched[i:i + 1])
+        if R != 1:
+            n = (2 + tape.pos * S * R + 63) // 64 * 64 + 8 * d * d
+            ws = torch.empty(n, dtype=torch.int32, device=gW.device)
+            a.pair_ws, a.pair_ws_len = ptr(ws), n
+        _call("ic_router_wgrad", a)
 
 
 # ============================================================================ gate
