@@ -190,7 +190,7 @@ class LoopEngine:
             return False
         if torch.is_grad_enabled() and logits_need_grad:
             return False
-        if m.cfg.profile or m.cfg.ff_dropout or m.router.edge_transform_mode == "factorized":
+        if m.cfg.profile or m.cfg.ff_dropout or (m.router.edge_transform_mode == "factorized" and not m.router.fact_lib):
             return False
         b = m.bank
         if b.S != 1 or b.num.device != H_prev.device:
@@ -318,12 +318,14 @@ class LoopEngine:
             sh.update(radius_o=((R,), _F32), radius_var_o=((R,), _F32), ynorm=((R,), _F32))
         if rt.enable_precision_routed_messages:
             sh.update(msg=((E, d), _F32), keyv=((E, d), _F32), q=rd, wgt=((E,), _F32))
+        if rt.fact_lib:  # factorized mode: V h of the senders, the mixed rows U applies to, rows with an active in-edge
+            sh.update(fact_t=rd, fact_z=rd, fact_dact=((R,), _U8))
         return sh
 
     def _get_arena(self, device, steps: int) -> StepArena:
         m = self.model
         key = (device, m.R, m.d, m.router.E, m.bank.afd, m.bank.rt, m.bank.use_pred,
-               m.router.enable_precision_routed_messages)
+               m.router.enable_precision_routed_messages, m.router.fact_lib)
         if self._arena is None or self._arena_key != key:
             self._arena = StepArena(self._shapes(), chunk_steps=max(128, 4 * steps))
             self._arena_key = key
@@ -332,7 +334,7 @@ class LoopEngine:
 
     def _workspace(self, device):
         """Backward scratch shared by all steps (the stream serialises them)."""
-        if self._ws is not None and self._ws["gM"].device == device:
+        if self._ws is not None and self._ws["gM"].device == device and ("fact_gz" in self._ws) == self.model.router.fact_lib:
             return self._ws
         m = self.model
         R, d, E = m.R, m.d, max(m.router.E, 1)
@@ -340,6 +342,8 @@ class LoopEngine:
         z = lambda *s: torch.zeros(*s, device=device)
         ws = {"gM": z(2, R, d), "ghpre": z(R, d), "slab2": z(ns, R, d), "slab": z(ns, R, d), "slab_rt": z(ns, R),
               "gH_tmp": z(2, R, d), "gHd": z(2, R, d), "rslab": z(ns, 2, E, d), "slab_q": z(ns, 2, R, d)}
+        if m.router.fact_lib:
+            ws.update(fact_gz=z(2, R, d), fact_gt=z(2, R, d), fact_slab=z(ns, 2, R, d), fact_gb=z(ns, 2, R))
         for side in ("a", "b"):
             for k in ("gnum", "gden", "gvar", "gpred"):
                 ws[f"{k}_{side}"] = z(R, d)
@@ -442,7 +446,7 @@ class LoopEngine:
             out_names += [("radius", "radius_o"), ("radius_var", "radius_var_o")]
         saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
             + (["sterm"] if afd else [])
-        rsaved = ["msg", "keyv", "q", "wgt"] if prec else []
+        rsaved = ["msg", "keyv", "q", "wgt"] if prec else (["fact_t", "fact_z", "fact_dact"] if router.fact_lib else [])
         denom = float(max(1, cfg.K_inner - 1))
         parent: List[int] = []
         step_pos_l: List[float] = []
@@ -1027,7 +1031,7 @@ class LoopEngine:
             return False
         if cfg.train_deterministic_inner_loop or cfg.B_br != 2 or m.plan is None or m.verify is None:
             return False
-        if cfg.profile or cfg.ff_dropout or m.router.edge_transform_mode == "factorized" or m.router.E <= 0:
+        if cfg.profile or cfg.ff_dropout or (m.router.edge_transform_mode == "factorized" and not m.router.fact_lib) or m.router.E <= 0:
             return False
         return True
 
@@ -1154,7 +1158,7 @@ class LoopEngine:
             ra = ops._router_args(rspec, tables, rP, C)
             ra.ebias, ra.H, ra.mask_prev = sb["ebias"].data_ptr(), CP["H"], CP["mask"]
             rimg = StructImage(ra)
-            for k_ in ["M"] + (["msg", "keyv", "q", "wgt"] if prec else []):
+            for k_ in ["M"] + (["msg", "keyv", "q", "wgt"] if prec else (["fact_t", "fact_z", "fact_dact"] if router.fact_lib else [])):
                 rimg.linear((k_,), CP[k_] + base * CS[k_], C * CS[k_])
             rimg.linear(("in_slot",), ctl_p + o_in, cw)
             r_rows = rimg.images(gs)
@@ -1396,7 +1400,7 @@ class LoopEngine:
         C = 1 if m.cfg.train_deterministic_inner_loop else max(1, m.cfg.B_br)
         if not self.enabled or dev.type != "cuda" or n_loops < 1 or C > 2:
             return False
-        if m.cfg.profile or m.cfg.ff_dropout or m.router.edge_transform_mode == "factorized":
+        if m.cfg.profile or m.cfg.ff_dropout or (m.router.edge_transform_mode == "factorized" and not m.router.fact_lib):
             return False
         if not m.cfg.train_deterministic_inner_loop and (m.plan is None or m.verify is None):
             return False
@@ -1555,7 +1559,7 @@ class LoopEngine:
             out_names += [("radius", "radius_o"), ("radius_var", "radius_var_o")]
         saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
             + (["sterm"] if afd else [])
-        rsaved = ["msg", "keyv", "q", "wgt"] if prec else []
+        rsaved = ["msg", "keyv", "q", "wgt"] if prec else (["fact_t", "fact_z", "fact_dact"] if router.fact_lib else [])
         denom = float(max(1, cfg.K_inner - 1))
         w5, w6 = gate.w5, gate.w6
         sync = torch.cuda.current_stream(dev).synchronize
@@ -1789,6 +1793,8 @@ class LoopEngine:
             zf["g_rnoise_rows"] = R * 2
         if prec:
             zf["g_rawP_rows"] = Ez * d
+        if router.fact_lib:
+            zf["g_fw_rows"] = Ez * d
         Z, zp = {}, {}
         pad = lambda n: (n + 63) // 64 * 64  # every field starts 256-byte aligned (float4 row stores)
         zall = torch.zeros(sum(pad(n_r * sz) for sz in zf.values()), device=dev)  # ONE fill for the whole loop
@@ -1830,11 +1836,13 @@ class LoopEngine:
             rb.f.M = WP["gM"]  # unused by the backward, must be non-NULL
             rb.src_off, rb.src_edges = tables["src_off"].data_ptr(), tables["src_edges"].data_ptr()
             rb.slab, rb.gHd, rb.slab_q = WP["rslab"], WP["gHd"], WP["slab_q"]
+            if router.fact_lib:
+                rb.fact_gz, rb.fact_gt, rb.fact_slab, rb.fact_gb = WP["fact_gz"], WP["fact_gt"], WP["fact_slab"], WP["fact_gb"]
         b_ref, rb_ref = ctypes.byref(b), ctypes.byref(rb)
         p_bwd, r_bwd = L.ic_region_phase_bwd, L.ic_router_bwd
         saved = ["x", "u1", "inv_s", "r_s", "k_s", "v_s", "y", "hpre", "gate"] + (["ynorm"] if rt_ else []) \
             + (["sterm"] if afd else [])
-        rsaved = ["msg", "keyv", "q", "wgt"] if prec else []
+        rsaved = ["msg", "keyv", "q", "wgt"] if prec else (["fact_t", "fact_z", "fact_dact"] if router.fact_lib else [])
         init = {k: v.data_ptr() for k, v in s.init.items()}
         state_in = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o")] + ([("var", "var_o")] if afd else []) \
             + ([("pred", "pred_o")] if use_pred else []) \
@@ -1897,8 +1905,11 @@ class LoopEngine:
             rimg.linear(("g_ebias_part",), zp["g_ebias_part"], ns * Ez * 4)
             if prec:
                 rimg.linear(("g_rawP_rows",), zp["g_rawP_rows"], Ez * d * 4)
+            if router.fact_lib:
+                rimg.linear(("g_fw_rows",), zp["g_fw_rows"], Ez * d * 4)
             for k, fld in (("gmsg", "tape_gmsg"), ("H", "tape_H"), ("eact", "tape_eact"), ("gkey", "tape_gkey"),
-                           ("gq", "tape_gq"), ("qact", "tape_qact")):
+                           ("gq", "tape_gq"), ("qact", "tape_qact"), ("gU", "tape_gU"), ("zU", "tape_zU"), ("aU", "tape_aU"),
+                           ("gV", "tape_gV"), ("aV", "tape_aV")):
                 if k in RB:
                     rimg.linear((fld,), RB[k][0] + rt0 * RB[k][1], RB[k][1])
             rb.gM = WP["gM"]
@@ -2019,13 +2030,15 @@ class LoopEngine:
     def _workspace_batch(self, device, V: int):
         m = self.model
         R, d, E = m.R, m.d, max(m.router.E, 1)
-        key = (device, V, R, d, E)
+        key = (device, V, R, d, E, m.router.fact_lib)
         if self._wsb is not None and self._wsb["_key"] == key:
             return self._wsb
         ns = ops.bwd_nslab(d)
         e = lambda *s: torch.empty(*s, device=device)
         ws = {"gM": e(V, R, d), "ghpre": e(V, R, d), "slab2": e(ns, V, R, d), "slab": e(ns, V, R, d),
               "slab_rt": e(ns, V, R), "gHd": e(V, R, d), "rslab": e(ns, V, E, d), "slab_q": e(ns, V, R, d)}
+        if m.router.fact_lib:
+            ws.update(fact_gz=e(V, R, d), fact_gt=e(V, R, d), fact_slab=e(ns, V, R, d), fact_gb=e(ns, V, R))
         for side in ("a", "b"):
             for k in ("gnum", "gden", "gvar", "gpred"):
                 ws[f"{k}_{side}"] = e(V, R, d)
@@ -2084,6 +2097,8 @@ class LoopEngine:
             zf["g_rnoise_rows"] = R * 2
         if prec:
             zf["g_rawP_rows"] = Ez * d
+        if router.fact_lib:
+            zf["g_fw_rows"] = Ez * d
         pad = lambda n: (n + 63) // 64 * 64
         zall = torch.zeros(sum(pad(V * sz) for sz in zf.values()), device=dev)
         Z, zp, zoff = {}, {}, 0
@@ -2177,17 +2192,22 @@ class LoopEngine:
             rb.f.H, rb.f.mask_prev = CP["H"] + base * CS["H"], CP["mask"] + base * CS["mask"]
             rb.src_off, rb.src_edges = tables["src_off"].data_ptr(), tables["src_edges"].data_ptr()
             rb.slab, rb.gHd, rb.slab_q = WP["rslab"], WP["gHd"], WP["slab_q"]
+            if router.fact_lib:
+                rb.fact_gz, rb.fact_gt, rb.fact_slab, rb.fact_gb = WP["fact_gz"], WP["fact_gt"], WP["fact_slab"], WP["fact_gb"]
             rb.gM, rb.gH, rb.sk = WP["gM"], zp["gH"], sS
             rimg = StructImage(rb)
-            for k in (["msg", "keyv", "q", "wgt"] if prec else []):
+            for k in (["msg", "keyv", "q", "wgt"] if prec else (["fact_t", "fact_z", "fact_dact"] if router.fact_lib else [])):
                 rimg.linear(("f", k), CP[k] + base * CS[k], tS * CS[k])
             # the kernel writes [ns, S*sk, Ez] partials per launch: interleaved over the steps when the loops sit
             # K slots apart ([ns, V, Ez] in all), one [ns, S, Ez] block per step when they run in lockstep
             rimg.linear(("g_ebias_part",), zp["g_ebias_part"], (ns * S * Ez if lock else Ez) * 4)
             if prec:
                 rimg.linear(("g_rawP_rows",), zp["g_rawP_rows"], tS * Ez * d * 4)
+            if router.fact_lib:
+                rimg.linear(("g_fw_rows",), zp["g_fw_rows"], tS * Ez * d * 4)
             for k, fld in (("gmsg", "tape_gmsg"), ("H", "tape_H"), ("eact", "tape_eact"), ("gkey", "tape_gkey"),
-                           ("gq", "tape_gq"), ("qact", "tape_qact")):
+                           ("gq", "tape_gq"), ("qact", "tape_qact"), ("gU", "tape_gU"), ("zU", "tape_zU"), ("aU", "tape_aU"),
+                           ("gV", "tape_gV"), ("aV", "tape_aV")):
                 if k in RB:
                     rimg.linear((fld,), RB[k][0] + rt0 * RB[k][1], tS * RB[k][1])
             rimg.linear(("in_slot",), in_slot.data_ptr(), S * 4)
@@ -2273,6 +2293,8 @@ class LoopEngine:
         if E > 0:
             if prec:
                 router._grad_sink("raw_P", tot("g_rawP_rows").sum(0).view(Ez, d)[:E], s0.keep[1]["widx_long"])
+            if router.fact_lib:
+                router._grad_sink("w_e", tot("g_fw_rows").sum(0).view(Ez, d)[:E], s0.keep[1]["widx_long"])
             if s0.ebias_grad:  # ebias = 1 + fb_alpha * fb_scale * sum_m(cos S * beta_cos + sin S * beta_sin)
                 g_eb = tot("g_ebias_part").view(-1, Ez).sum(0)[:E] * (router.fb_alpha * router.fb_scale)
                 _, cosS, sinS = router._geom

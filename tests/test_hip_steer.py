@@ -65,7 +65,7 @@ def assert_same(a, b):
         assert va == vb
 
 
-@pytest.mark.parametrize("name", ["default", "allflags", "kactive2", "softkwta", "afdvec", "bench10m"])
+@pytest.mark.parametrize("name", ["default", "allflags", "kactive2", "softkwta", "afdvec", "bydir", "bydir_prec", "factorized", "bench10m"])
 def test_steered_train_steps_equal_host_steered(name):
     a, ca, la, na = run_steps(name, True)
     b, cb, lb, nb = run_steps(name, False)

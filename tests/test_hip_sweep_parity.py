@@ -321,3 +321,65 @@ def test_router_by_direction_mfma_vs_oracle(R, S, d):
     zeros = torch.zeros(d, d)
     gclose(gW, torch.stack([P["W_dir"][k].grad if P["W_dir"][k].grad is not None else zeros for k in range(6)]), what="g.W_dir")
     PL.flush(_TAG[0])
+
+
+@pytest.mark.parametrize("R,S,d", [(36, 4, 256), (64, 8, 256), (10, 3, 48)])
+def test_router_factorized_lib_vs_oracle(R, S, d, monkeypatch):
+    """edge_transform_mode="factorized" (gate.py:150-159,278-281) on the library (IC_RF_FACTORIZED): V h per active
+    sender and U z per destination as shared-matrix fp32-MFMA GEMMs, the per-edge diagonal in the mix kernels, dU / dV
+    through the deterministic shared weight-gradient GEMM -- against the per-stream oracle (which applies U per EDGE,
+    as the reference does), bit-identical from run to run; w_e of an inactive edge keeps grad None."""
+    from ironcortex_amd.gate import Router
+    from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
+    from oracle import hotpath as O
+    seed = 8100 + R + S
+    nb = hex_neighbors(R)
+    coords = hex_axial_coords(R)
+    router = Router(nb, d, R, edge_transform_mode="factorized").to(DEV)
+    assert router.fact_lib
+    monkeypatch.setattr(router, "_route_factorized", None)  # the PyTorch formulation must not be the path taken
+    E = router.E
+    U, V = gi.det(seed + 1, d, d, kind="xavier"), gi.det(seed + 2, d, d, kind="xavier")
+    w_e = 1.0 + gi.det(seed + 3, E, d, scale=0.3)
+    t = dict(W_reg=gi.det(seed + 5, 8, 2), beta_cos=gi.det(seed + 6, 8, scale=0.3), beta_sin=gi.det(seed + 7, 8, scale=0.3))
+    with torch.no_grad():
+        router.U.weight.copy_(U); router.V.weight.copy_(V)
+        for e, k in enumerate(router.edge_keys):
+            router.w_edge[k].copy_(w_e[e])
+        router.W_reg.copy_(t["W_reg"]); router.beta_cos.copy_(t["beta_cos"]); router.beta_sin.copy_(t["beta_sin"])
+    mask = gi.det(seed + 4, S, R, kind="rand") < 0.45
+    mask[S - 1] = False
+    H = gi.det(seed + 8, S, R, d) * mask.unsqueeze(-1)
+    gM = gi.det(seed + 9, S, R, d)
+    runs = []
+    for _ in range(2):
+        for p in router.parameters():
+            p.grad = None
+        Hg = H.to(DEV).requires_grad_(True)
+        M = router.route(Hg, mask.to(torch.uint8).to(DEV), coords.to(DEV))
+        (M * gM.to(DEV)).sum().backward()
+        gw = torch.stack([router.w_edge[k].grad.clone() if router.w_edge[k].grad is not None else torch.zeros(d, device=DEV)
+                          for k in router.edge_keys])
+        runs.append((M.detach().clone(), Hg.grad.clone(), router.U.weight.grad.clone(), router.V.weight.grad.clone(), gw))
+    for a_, b_ in zip(runs[0], runs[1]):
+        assert torch.equal(a_, b_), "not reproducible from run to run"
+    M, gH, gU, gV, gw = runs[0]
+    assert torch.all(M[S - 1] == 0)
+    leaf = lambda x: x.clone().requires_grad_(True)
+    P = {"U": leaf(U), "V": leaf(V), "w_edge": [leaf(w_e[e]) for e in range(E)], "W_reg": t["W_reg"],
+         "beta_cos": leaf(t["beta_cos"]), "beta_sin": leaf(t["beta_sin"])}
+    Hc = H.clone().requires_grad_(True)
+    Mc = torch.stack([O.router_messages(P, Hc[s], mask[s], coords, nb, mode="factorized")[0] for s in range(S)])
+    (Mc * gM).sum().backward()
+    _TAG[0] = f"factorized-lib/R{R}/S{S}/d{d}"
+    close(M, Mc, what="M")
+    gclose(gH, Hc.grad, what="g.H")
+    gclose(router.beta_cos.grad, P["beta_cos"].grad, what="g.beta_cos")
+    gclose(router.beta_sin.grad, P["beta_sin"].grad, what="g.beta_sin")
+    gclose(gU, P["U"].grad, what="g.U")
+    gclose(gV, P["V"].grad, what="g.V")
+    gclose(gw, torch.stack([P["w_edge"][e].grad if P["w_edge"][e].grad is not None else torch.zeros(d) for e in range(E)]), what="g.w_edge")
+    act = mask[:, router.src_idx.cpu()].any(0)
+    for e, k in enumerate(router.edge_keys):
+        assert (router.w_edge[k].grad is not None) == bool(act[e]), k
+    PL.flush(_TAG[0])
