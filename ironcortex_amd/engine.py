@@ -1717,6 +1717,9 @@ class LoopEngine:
         for j in range(N):
             traces.append(list(tr_rows[o_:o_ + len(trace_steps[j])].unbind(0)))
             o_ += len(trace_steps[j])
+        if m._units is not None:  # bench / sweep unit counters: executed (loop, step) pairs' active regions
+            ex = torch.tensor([base + t * N + j for j in range(N) for t in range(n_steps[j])], device=dev)
+            m._units[0] += f["mask"][ex].sum().float()
         jl = N - 1
         li = base + (n_steps[jl] - 1) * N + jl
         nar = torch.narrow

@@ -109,6 +109,20 @@ def lib():
         _lib.ic_loop_step_fwd.argtypes = [vp, vp, vp, vp]
         _lib.ic_heads_gemv_fwd.argtypes = [vp, vp, vp, vp]
         _lib.ic_verify_score.argtypes = [vp, ctypes.c_int32, vp, vp, vp]
+        # entry points that take bare pointers and scalars: declared in full, so that a Python int handed over as a
+        # device address can never be truncated to a C int (a 32-bit "pointer" reaching a kernel is a GPU memory fault)
+        i32, f32 = ctypes.c_int32, ctypes.c_float
+        _lib.ic_kwta_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp]
+        _lib.ic_kwta_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
+        _lib.ic_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
+        _lib.ic_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
+        _lib.ic_goodness_fwd.argtypes = [vp, vp, i32, i32, vp]
+        _lib.ic_goodness_bwd.argtypes = [vp, vp, vp, i32, i32, vp]
+        _lib.ic_hebbian_rank1.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        for fn_ in ("ic_region_phase_fwd", "ic_region_phase_bwd", "ic_region_wgrad", "ic_router_fwd", "ic_router_bwd", "ic_router_wgrad",
+                    "ic_gate_scores", "ic_gate_select", "ic_gate_fwd", "ic_heads_fwd", "ic_heads_fwd_static", "ic_steer_select",
+                    "ic_loop_steer", "ic_linear_bwd", "ic_attn_fwd", "ic_attn_bwd"):
+            getattr(_lib, fn_).argtypes = [vp, vp]  # (struct pointer, stream)
         _lib.ic_graph_begin.argtypes = [vp]
         _lib.ic_graph_end.argtypes = [vp, vp, vp]
         _lib.ic_graph_launch.argtypes = [vp, vp]

@@ -63,7 +63,17 @@ def flush_before_backward(on: bool) -> None:
     ops._call = call
 
 
-def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
+MARK_BASE = 1000  # marker launches (k_kwta_rows with 4 * (MARK_BASE + id) rows): id = point index before the timed
+                  # iterations of a point, 4000 + index after them; scripts/sweep_grid.py splits a kernel trace by them
+
+
+def mark(idx: int) -> None:
+    from ironcortex_amd.utils import KWTA
+    with torch.no_grad():
+        KWTA(torch.zeros(4 * (MARK_BASE + idx), 8, device="cuda"), 2)
+
+
+def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True, markers=False):
     """Yields one dict per (R, S, k) point.  events=False: no HIP-event bracketing (the run is being
     traced by rocprofv3 instead); the row then only carries the algorithmic bytes."""
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -110,8 +120,13 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
                     hip.prof_select("")
                     hip.prof_enable(True)
                     hip.prof_read()
+                if markers:
+                    mark(_POINT[0])
                 for i in range(iters):
                     run(backward, 3 + i)
+                if markers:
+                    mark(4000 + _POINT[0])
+                    _POINT[0] += 1
                 torch.cuda.synchronize()
                 prof = hip.prof_read() if events else {}
                 hip.prof_enable(False)
@@ -141,6 +156,7 @@ def sweep(Rs, ks, Ss, d=256, iters=20, backward=False, rotate=1, events=True):
         torch.cuda.empty_cache()
 
 
+_POINT = [0]
 PRECISION = False  # --precision: precision-routed messages (key / query GEMVs + softmax combine)
 SWEEP_KERNELS = ("region_pro", "region_rkv", "region_state", "region_out", "region_fin", "router_fwd", "router_edge_fwd", "router_combine", "region_out_bwd", "region_rkv_bwd",
                  "region_mid_bwd", "region_pro_bwd", "router_mat_bwd", "router_gather_bwd", "wgrad_region", "wgrad_edge")
@@ -158,11 +174,12 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="no HIP-event bracketing (run under rocprofv3)")
     ap.add_argument("--precision", action="store_true")
     ap.add_argument("--flush-bwd", action="store_true", help="1 GiB read before every backward entry point (see flush_before_backward)")
+    ap.add_argument("--markers", action="store_true", help="marker launches around every point's timed iterations (scripts/sweep_grid.py)")
     args = ap.parse_args()
     global PRECISION
     PRECISION = args.precision
     flush_before_backward(args.flush_bwd)
-    for row in sweep(args.R, args.k, args.S, args.d, args.iters, args.backward, args.rotate, not args.no_events):
+    for row in sweep(args.R, args.k, args.S, args.d, args.iters, args.backward, args.rotate, not args.no_events, args.markers):
         print(json.dumps(row), flush=True)
 
 
