@@ -99,6 +99,15 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     neg_tokens, focus_neg, d_targets, d_masks, is_real = make_negatives(clean_tokens, model.V)
     tokens_all = torch.cat([clean_tokens, neg_tokens], dim=0)
     focus_all = torch.cat([torch.zeros_like(focus_neg, dtype=torch.bool), focus_neg], dim=0)
+    # every host->device copy of the step happens HERE, before the loops are enqueued: a copy from pageable memory waits
+    # for the stream, and one issued after the loops would hold the host until they finish (8 ms in which the loss ops,
+    # the whole backward and the optimizer step could have been enqueued behind them)
+    rtd_target = (~torch.tensor(is_real, device=device)).long()
+    d_rows = [b for b in range(B) if bool(d_masks[b].any())]  # host tensors: no device sync
+    if d_rows:
+        d_first = [int(d_masks[b].nonzero(as_tuple=False)[0].item()) for b in d_rows]
+        d_pack = torch.stack([torch.stack([d_targets[b][i] for b, i in zip(d_rows, d_first)]).long(), torch.tensor(d_rows)]).to(device)
+    zero = torch.zeros((), device=device)
     # no loss below back-propagates through the inner-step logits / workspace (training.py:120-231):
     # the loops may run on the LoopEngine (one autograd node per loop)
     model.engine.new_step()
@@ -122,7 +131,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         aux_neg = torch.stack([energy_all[B:], ms, entropy_all[B:]], dim=-1)
 
     # ---- FF per-region losses on the final states (training.py:120-156), batched over regions
-    ff_loss = torch.tensor(0.0, device=device)
+    ff_loss = zero
     gains = None
     if cfg.enable_forward_forward:
         gpos = ops.GoodnessFn.apply(H_pos) - lam_s * surprise  # [B,R]
@@ -148,25 +157,20 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     motor = model.io_idxs["motor"]
     motor_pos, motor_neg = H_pos[:, motor, :], H_neg[:, motor, :]
     rtd_logits = model.rtdd(motor_neg)
-    rtd_target = (~torch.tensor(is_real, device=device)).long()
     rtd_loss = F.cross_entropy(rtd_logits, rtd_target)
     rtd_acc = (rtd_logits.argmax(dim=-1) == rtd_target).float().mean()
 
     # ---- denoising (mask-predict): first masked position of each negative (training.py:170-186);
     # the token head runs once for all rows instead of once per sample
-    denoise_loss = torch.tensor(0.0, device=device)
-    denoise_acc = torch.tensor(0.0, device=device)
-    rows = [b for b in range(B) if bool(d_masks[b].any())]  # host tensors: no device sync
-    if rows:
-        first = [int(d_masks[b].nonzero(as_tuple=False)[0].item()) for b in rows]
-        target = torch.stack([d_targets[b][i] for b, i in zip(rows, first)]).to(device)
-        sel = torch.tensor(rows, device=device)
+    denoise_loss = denoise_acc = zero
+    if d_rows:
+        target, sel = d_pack[0], d_pack[1]
         logits_d, facet = model.lm_head.forward_rows(motor_neg[sel])
         denoise_loss = (F.cross_entropy(logits_d, target, reduction="sum") + λ.facet * facet.sum()) / max(1, B)
         denoise_acc = (logits_d.argmax(dim=-1) == target).float().mean()
 
     # ---- critic regression
-    critic_loss = torch.tensor(0.0, device=device)
+    critic_loss = zero
     if not cfg.train_deterministic_inner_loop:
         realized = (H_pos.pow(2).mean(dim=-1).mean(dim=-1) - H_neg.pow(2).mean(dim=-1).mean(dim=-1)).detach()
         on = mask_n.to(H_neg.dtype)
@@ -191,7 +195,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
             model.verify_state.update_tau(0.5 * (model.E_pos_mean + model.E_neg_mean))
     else:
         E_pos, E_neg = torch.zeros(B, device=device), torch.zeros(B, device=device)
-        verifier_loss = torch.tensor(0.0, device=device)
+        verifier_loss = zero
 
     total = λ.ff * ff_loss + λ.rtd * rtd_loss + λ.denoise * denoise_loss + λ.critic * critic_loss + λ.verify * verifier_loss
     if dp is not None:
@@ -206,7 +210,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         dp.sync_grads(model)
     with torch.no_grad():
         grads = [p.grad for p in _parameters(model) if p.grad is not None]
-        grad_norm = torch.stack(torch._foreach_norm(grads)).pow(2).sum().sqrt() if grads else torch.tensor(0.0, device=device)
+        grad_norm = torch.stack(torch._foreach_norm(grads)).pow(2).sum().sqrt() if grads else zero
         # Hebbian nudges on edges whose two ends were active in a positive sample (training.py:147-156,240-243)
         if gains is not None and model.router.E > 0:
             router = model.router

@@ -1,0 +1,52 @@
+"""Host clock and GPU clock (HIP events) at the same markers of one train_step: where the GPU runs behind the host the
+step is GPU-bound, where the two advance together the host is the limit.  No tracing tool involved."""
+import os, sys, time, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ironcortex_amd as ic
+from ironcortex_amd import engine as E, training as T
+from bench import make_config
+dev = torch.device("cuda:0")
+cfg = make_config(sys.argv[1] if len(sys.argv) > 1 else "10m")
+torch.manual_seed(0); random.seed(0)
+m = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg).to(dev)
+opt = torch.optim.AdamW(m.parameters(), lr=1e-3, fused=True)
+toks = torch.randint(0, 255, (8, 256), device=dev)
+marks = []
+def mark(name):
+    ev = torch.cuda.Event(enable_timing=True); ev.record()
+    marks.append((name, time.perf_counter(), ev))
+def wrap(obj, attr, name):
+    f = getattr(obj, attr)
+    def w(*a, **k):
+        mark(name + ">"); r = f(*a, **k); mark(name + "<"); return r
+    setattr(obj, attr, w)
+wrap(T, "make_negatives", "make_negatives")
+wrap(m, "sensor_vectors_batch", "mixer")
+wrap(m.engine, "run_steered", "run_steered")
+wrap(m.engine, "backward_batch", "backward_batch")
+wrap(m._coord, "_end", "coord_end")
+wrap(opt, "step", "opt.step")
+wrap(opt, "zero_grad", "zero_grad")
+wrap(m, "finalize_grads", "finalize_grads")
+ob = torch.Tensor.backward
+def tb(self, *a, **k):
+    mark("backward>"); r = ob(self, *a, **k); mark("backward<"); return r
+torch.Tensor.backward = tb
+for _ in range(4):
+    ic.train_step(m, opt, toks, ic.LossWeights(), dev)
+torch.cuda.synchronize()
+rows = []
+for rep in range(5):
+    marks.clear()
+    torch.cuda.synchronize()
+    mark("step>")
+    ic.train_step(m, opt, toks, ic.LossWeights(), dev)
+    mark("step<")
+    torch.cuda.synchronize()
+    t0, e0 = marks[0][1], marks[0][2]
+    rows.append([(n, 1e3 * (t - t0), e0.elapsed_time(ev)) for n, t, ev in marks])
+best = min(rows, key=lambda r: r[-1][1])
+print(f"{'marker':22s} {'host ms':>9s} {'gpu ms':>9s} {'gpu behind':>10s}")
+for n, h, g in best:
+    print(f"{n:22s} {h:9.3f} {g:9.3f} {g - h:10.3f}")
