@@ -80,6 +80,7 @@ class FlatParams:
         self.total = off
         self.flat: torch.Tensor = None  # type: ignore
         self.gflat: torch.Tensor = None  # type: ignore
+        self._gviews, self._gviews_of = {}, None
         self.reflat(force=True)
 
     # ------------------------------------------------------------------ storage
@@ -119,6 +120,7 @@ class FlatParams:
                 p.grad = None
         self.flat = flat
         self.gflat = None
+        self._gviews, self._gviews_of = {}, None
 
     def stacked(self, name: str) -> torch.Tensor:
         off, numel, shape = self.layout[name]
@@ -153,8 +155,13 @@ class FlatParams:
 
     def publish(self, name: str, touched: Sequence[bool]) -> None:
         """Give .grad views to the touched members of a group (untouched keep None)."""
-        off, numel, shape = self.layout[name]
         g = self.grad_arena()
-        for i, p in enumerate(self.groups[name]):
-            if touched[i] and p.grad is None and p.requires_grad:
-                p.grad = g[off + i * numel: off + (i + 1) * numel].view(shape)
+        views = self._gviews.get(name) if self._gviews_of is g else None
+        if views is None:  # the views of one arena never change: built once (slicing costs ~2.5 us each, every step)
+            if self._gviews_of is not g:
+                self._gviews, self._gviews_of = {}, g
+            off, numel, shape = self.layout[name]
+            views = self._gviews[name] = [g[off + i * numel: off + (i + 1) * numel].view(shape) for i in range(len(self.groups[name]))]
+        for p, v, t in zip(self.groups[name], views, touched):
+            if t and p.grad is None and p.requires_grad:
+                p.grad = v

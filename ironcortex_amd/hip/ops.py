@@ -61,6 +61,10 @@ class GradCoordinator:
         self._flagged: List[tuple] = []  # (launch() -> Optional[uint8 tensor], publish(list of bool))
         self.dp = None
         self.extra_params: Optional[Callable[[], list]] = None
+        # defer (train_step sets it around its backward): the end of the pass launches the deferred work but leaves the
+        # one host read of the flags to an explicit publish(), so that the caller can enqueue more work in between
+        self.defer = False
+        self._held = None
 
     def register(self, begin: Callable[[], None], finish: Callable[[], None]) -> None:
         self._begin.append(begin)
@@ -84,27 +88,39 @@ class GradCoordinator:
             flags = [launch() for launch, _ in self._flagged]
             for f in self._finish:
                 f()
-            extra = self.extra_params() if (self.dp is not None and self.extra_params is not None) else []
-            parts = [t.reshape(-1) for t in flags if t is not None]
-            if extra:
-                parts.append(torch.tensor([0 if p.grad is None else 1 for p in extra], dtype=torch.uint8,
-                                          device=extra[0].device))
-            if not parts:
-                return
-            allf = torch.cat(parts)
-            if self.dp is not None:
-                allf = self.dp.any_flags(allf)
-            host = allf.bool().tolist()  # the one host sync of the backward pass
-            off = 0
-            for (_, publish), t in zip(self._flagged, flags):
-                if t is not None:
-                    publish(host[off:off + t.numel()])
-                    off += t.numel()
-            for p, h in zip(extra, host[off:]):
-                if h and p.grad is None:
-                    p.grad = torch.zeros_like(p)
+            if self.defer:
+                self._held = flags
+            else:
+                self._publish(flags)
         finally:
             self._pending = False
+
+    def publish(self) -> None:
+        """The host read a deferred pass left open (no-op otherwise)."""
+        held, self._held = self._held, None
+        if held is not None:
+            self._publish(held)
+
+    def _publish(self, flags) -> None:
+        extra = self.extra_params() if (self.dp is not None and self.extra_params is not None) else []
+        parts = [t.reshape(-1) for t in flags if t is not None]
+        if extra:
+            parts.append(torch.tensor([0 if p.grad is None else 1 for p in extra], dtype=torch.uint8,
+                                      device=extra[0].device))
+        if not parts:
+            return
+        allf = torch.cat(parts)
+        if self.dp is not None:
+            allf = self.dp.any_flags(allf)
+        host = allf.bool().tolist()  # the one host sync of the backward pass
+        off = 0
+        for (_, publish), t in zip(self._flagged, flags):
+            if t is not None:
+                publish(host[off:off + t.numel()])
+                off += t.numel()
+        for p, h in zip(extra, host[off:]):
+            if h and p.grad is None:
+                p.grad = torch.zeros_like(p)
 
     def abort(self) -> bool:
         """A backward pass that raised never reaches its end-of-pass callback, which would leave
@@ -112,6 +128,7 @@ class GradCoordinator:
         gradients).  Called at a known boundary -- the start of a train_step / LoopEngine.reset():
         no pass can be in flight there, so a set flag is a stale one.  Returns True if it was."""
         stale, self._pending = self._pending, False
+        self._held = None
         return stale
 
 

@@ -198,11 +198,42 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         verifier_loss = zero
 
     total = λ.ff * ff_loss + λ.rtd * rtd_loss + λ.denoise * denoise_loss + λ.critic * critic_loss + λ.verify * verifier_loss
+    coord = model._coord
     if dp is not None:
         dp.attach(model)  # None-ness of every gradient made rank-consistent inside the backward's one host read
+    coord.defer = True  # the backward's one host read waits until the updates below have been enqueued behind it
     try:
         total.backward()
+        with torch.no_grad():
+            # Hebbian nudges on edges whose two ends were active in a positive sample (training.py:147-156,240-243)
+            if gains is not None and model.router.E > 0:
+                router = model.router
+                t = router._edge_tables(model.reg_coords)
+                Hh = H_pos.detach()
+                mp = mask_p.to(H_pos.dtype)
+                if dp is not None:  # every rank applies the whole global batch's nudges
+                    Hh, mp = dp.gather(Hh), dp.gather(mp)
+                coef = (1e-3 * gains.clamp_min(0.0))[router.dst_idx].unsqueeze(0) * mp[:, router.dst_idx] * mp[:, router.src_idx]
+                if router.edge_transform_mode != "per_edge":
+                    # the reference indexes router.W_edge here, which only per_edge mode defines (gate.py:136-137): it raises
+                    # as soon as ONE update is due (positive gain, region and a neighbour active in a positive sample) --
+                    # after the backward and the gain / tau updates, before homeostasis and the optimizer step.  Mirrored.
+                    if bool(((gains > 0)[router.dst_idx].unsqueeze(0) & (mp[:, router.dst_idx] > 0) & (mp[:, router.src_idx] > 0)).any()):
+                        raise AttributeError("'Router' object has no attribute 'W_edge' (edge_transform_mode="
+                                             f"{router.edge_transform_mode!r}; reference training.py:240-243)")
+                else:
+                    ops.hebbian_rank1(router._flat.stacked("W"), t["dst_of_edge"], t["src"], t["widx"], coef, Hh)
+                    if model._units is not None:  # bench.py's device-side unit counters: edges this launch updates
+                        model._units[14:16] += torch.stack([torch.ones((), device=coef.device), (coef != 0).any(0).sum().float()])
+            active_frac = mask_n.float().mean()
+            fired = mask_n.any(dim=0)
+            model.gate.update_homeo(dp.any(fired) if dp is not None else fired)
+            scalars = [t.detach().float().reshape(()) for t in (
+                ff_loss, rtd_loss, denoise_loss, critic_loss, verifier_loss, E_pos.mean(), E_neg.mean(), rtd_acc,
+                denoise_acc, active_frac, ce_loss, total)]
     finally:
+        coord.defer = False
+        coord.publish()  # (also on the way out of the mirrored AttributeError: the gradients exist by then, as in the reference)
         if dp is not None:
             dp.detach(model)
     model.finalize_grads()
@@ -211,35 +242,10 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     with torch.no_grad():
         grads = [p.grad for p in _parameters(model) if p.grad is not None]
         grad_norm = torch.stack(torch._foreach_norm(grads)).pow(2).sum().sqrt() if grads else zero
-        # Hebbian nudges on edges whose two ends were active in a positive sample (training.py:147-156,240-243)
-        if gains is not None and model.router.E > 0:
-            router = model.router
-            t = router._edge_tables(model.reg_coords)
-            Hh = H_pos.detach()
-            mp = mask_p.to(H_pos.dtype)
-            if dp is not None:  # every rank applies the whole global batch's nudges
-                Hh, mp = dp.gather(Hh), dp.gather(mp)
-            coef = (1e-3 * gains.clamp_min(0.0))[router.dst_idx].unsqueeze(0) * mp[:, router.dst_idx] * mp[:, router.src_idx]
-            if router.edge_transform_mode != "per_edge":
-                # the reference indexes router.W_edge here, which only per_edge mode defines (gate.py:136-137): it raises
-                # as soon as ONE update is due (positive gain, region and a neighbour active in a positive sample) --
-                # after the backward and the gain / tau updates, before homeostasis and the optimizer step.  Mirrored.
-                if bool(((gains > 0)[router.dst_idx].unsqueeze(0) & (mp[:, router.dst_idx] > 0) & (mp[:, router.src_idx] > 0)).any()):
-                    raise AttributeError("'Router' object has no attribute 'W_edge' (edge_transform_mode="
-                                         f"{router.edge_transform_mode!r}; reference training.py:240-243)")
-            else:
-                ops.hebbian_rank1(router._flat.stacked("W"), t["dst_of_edge"], t["src"], t["widx"], coef, Hh)
-                if model._units is not None:  # bench.py's device-side unit counters: edges this launch updates
-                    model._units[14:16] += torch.stack([torch.ones((), device=coef.device), (coef != 0).any(0).sum().float()])
-        active_frac = mask_n.float().mean()
-        fired = mask_n.any(dim=0)
-        model.gate.update_homeo(dp.any(fired) if dp is not None else fired)
     optimizer.step()
     if cfg.profile and cfg.profile_every_n_steps > 0 and step % cfg.profile_every_n_steps == 0:
         model.report_profile()
-    vals = torch.stack([t.detach().float().reshape(()) for t in (
-        ff_loss, rtd_loss, denoise_loss, critic_loss, verifier_loss, E_pos.mean(), E_neg.mean(), rtd_acc,
-        denoise_acc, grad_norm, active_frac, ce_loss, total)]).tolist()  # one host sync for all metrics
+    vals = torch.stack(scalars[:9] + [grad_norm.float().reshape(())] + scalars[9:]).tolist()  # one host sync for all metrics
     model.engine.resolve_open()  # (device-steered loops: their host-side record, now that the step has been waited for)
     keys = ("ff", "rtd", "denoise", "critic", "verify", "E_pos", "E_neg", "rtd_acc", "denoise_acc", "grad_norm",
             "active_frac", "ce_last", "total")

@@ -26,6 +26,7 @@ wrap(m, "sensor_vectors_batch", "mixer")
 wrap(m.engine, "run_steered", "run_steered")
 wrap(m.engine, "backward_batch", "backward_batch")
 wrap(m._coord, "_end", "coord_end")
+wrap(m._coord, "publish", "publish")
 wrap(opt, "step", "opt.step")
 wrap(opt, "zero_grad", "zero_grad")
 wrap(m, "finalize_grads", "finalize_grads")
