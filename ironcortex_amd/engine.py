@@ -229,8 +229,51 @@ class LoopEngine:
         """Host-side bookkeeping of the last device-steered batch, if nobody asked for it yet (its backward pass runs
         from the device-side record): read here, when the step that ran it has long been waited for."""
         bt, self._steered_open = getattr(self, "_steered_open", None), None
-        if bt is not None:
+        if bt is None:
+            return
+        sp = bt.get("steered")
+        if sp is None or self.model._units is not None or sp.get("counted"):
             self.resolve_steered(bt)
+            return
+        # nobody asked for the loops' host-side samples: all the step still owes is the inner-step count and the critic
+        # value the last iteration ran with (the full record stays available: resolve_steered(bt))
+        self._steered_light(bt)
+
+    def prefetch_open(self) -> None:
+        """Start the copy of the open batch's device-side record into pinned host memory (train_step calls this before
+        its one wait for the step, so that resolve_open finds the record on the host)."""
+        bt = getattr(self, "_steered_open", None)
+        sp = bt.get("steered") if bt is not None else None
+        if sp is None or "host" in sp:
+            return
+        sb = sp["sb"]
+        pin = getattr(self, "_pin_rec", None)
+        if pin is None or pin[0].shape != sb["ctl"].shape or pin[1].shape != sb["rec"].shape:
+            pin = self._pin_rec = (torch.empty(sb["ctl"].shape, dtype=sb["ctl"].dtype).pin_memory(),
+                                   torch.empty(sb["rec"].shape, dtype=sb["rec"].dtype).pin_memory())
+        pin[0].copy_(sb["ctl"], non_blocking=True)
+        pin[1].copy_(sb["rec"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        sp["host"] = (pin[0], pin[1], ev)
+
+    def _steered_record(self, sp):
+        """(ctl, rec) of a steered batch as numpy arrays: from the prefetched pinned copy when there is one."""
+        host = sp.pop("host", None)
+        if host is not None:
+            host[2].synchronize()
+            return host[0].numpy().copy(), host[1].numpy().copy()  # (the pinned buffers are reused by the next step)
+        sb = sp["sb"]
+        return sb["ctl"].cpu().numpy(), sb["rec"].cpu().numpy()  # (waits for the stream)
+
+    def _steered_light(self, bt) -> None:
+        m, sp = self.model, bt["steered"]
+        K, N = sp["K"], bt["n_loops"]
+        ctl, rec = self._steered_record(sp)
+        sp["counted"] = True
+        m.counters["inner_steps"] += int(rec[:N, 2].sum())
+        last = ctl[(N - 1) * K + max(0, int(rec[N - 1, 3]) - 1)]
+        m.gate.value_bias = float(np.array([last[ENUMS["IC_CTL_VHAT"]]], dtype=np.int32).view(np.float32)[0])
 
     def new_step(self) -> None:
         """train_step's first call.  A backward pass that raised (OOM, an ic_* error code, a user
@@ -1351,8 +1394,8 @@ class LoopEngine:
         sb, K, C, Z = sp["sb"], sp["K"], sp["C"], sp["Z"]
         chunk, base, KC, N = bt["chunk"], bt["base"], bt["n_max"], bt["n_loops"]
         f = chunk.fields
-        ctl = sb["ctl"].cpu().numpy()  # (waits for the stream)
-        rec = sb["rec"].cpu().numpy()
+        ctl, rec = self._steered_record(sp)
+        counted = sp.get("counted", False)  # (resolve_open's light path has already booked the counters)
         DEAD, TOP, VH = ENUMS["IC_CTL_DEAD"], ENUMS["IC_CTL_TOP"], ENUMS["IC_CTL_VHAT"]
         samples, n_inner = [], 0
         step_pos_all = [float(t // C) / sp["denom"] for t in range(KC)]
@@ -1387,6 +1430,8 @@ class LoopEngine:
             if m._units is not None:
                 self._unit_log.append((chunk, i0, list(parent), f["mask"][Z]))
         bt["samples"] = samples
+        if counted:
+            return
         m.counters["inner_steps"] += n_inner
         # what the host-steered loop leaves in the gate: the critic value its last iteration ran with
         last = ctl[(N - 1) * K + max(0, int(rec[N - 1, 3]) - 1)]
@@ -2147,6 +2192,24 @@ class LoopEngine:
                 r_live = [any(p >= 0 for p in col) for col in zip(*pars)]                     # host: per step
             in_slot = slot.t().contiguous().to(torch.int32)                                   # [K,S]
             rtape.visited[rt0:rt0 + V].copy_(to_v((slot >= 0).to(_U8)))
+        if sp is not None and t0 == 0 and (E == 0 or (rt0 == 0 and not router.fact_lib)):
+            # Which matrices this pass will touch follows from the forward's masks: the flags the deferred weight-gradient
+            # launches raise at the END of the pass (region r active in a step that reaches the loss; edge e with an
+            # active sender in the parent of such a step) go to the host NOW, behind the loops and ahead of the backward
+            # kernels, so that the end of the pass need not wait for the device before .grad views are handed out.
+            early = {bank._launch_wgrad: mk.amax((0, 1))}
+            if E > 0:
+                allm = chunk.fields["mask"][base:base + V]                                        # [V,R] by slot
+                pa = (allm[slot.clamp_min(0).reshape(-1)] * (slot >= 0).reshape(-1, 1).to(_U8)).amax(0)   # [R]
+                te = pa[router.src_idx].int()                                                     # [E]
+                wl = s0.keep[1]["widx_long"]
+                tw = torch.zeros(router.nW, dtype=torch.int32, device=dev).index_add_(0, wl, te).gt(0).to(_U8)
+                if prec:
+                    tq = torch.zeros(R, dtype=torch.int32, device=dev).index_add_(0, router.dst_idx, te).gt(0).to(_U8)
+                    tw = torch.cat([tw, tw, tq])
+                early[router._launch_wgrad] = tw
+            rtp = router._tape if E > 0 else None
+            m._coord.offer_early(early, lambda: tape.pos == V and (rtp is None or (router._tape is rtp and rtp.pos == V)))
 
         # ---- structs
         tables, rP, bP = s0.keep[1], s0.keep[2], s0.keep[3]

@@ -54,6 +54,8 @@ class GradCoordinator:
     across ranks in the same exchange, so that None-ness is identical on every rank without a
     host read of its own; a parameter another rank has a gradient for gets a zero gradient here."""
 
+    check_early = False  # (tests set it on the class: the device flags are read as well and compared with the early ones)
+
     def __init__(self):
         self._pending = False
         self._begin: List[Callable[[], None]] = []
@@ -65,6 +67,12 @@ class GradCoordinator:
         # one host read of the flags to an explicit publish(), so that the caller can enqueue more work in between
         self.defer = False
         self._held = None
+        # early flags (offer_early): a caller that knows which matrices a pass will touch before the pass has run hands
+        # the flags over at that point; they travel to pinned host memory behind it, and the end of the pass finds them
+        # there instead of waiting for the device
+        self._early = None
+        self._pinned: Optional[torch.Tensor] = None
+        self.early_used = 0
 
     def register(self, begin: Callable[[], None], finish: Callable[[], None]) -> None:
         self._begin.append(begin)
@@ -83,15 +91,40 @@ class GradCoordinator:
             f()
         torch.autograd.Variable._execution_engine.queue_callback(self._end)
 
+    def offer_early(self, flags: Dict[Callable, Optional[torch.Tensor]], valid: Callable[[], bool]) -> None:
+        """flags: launch function of a flagged participant -> the uint8 flags its launch will return at the end of this
+        pass (None where it will return None); valid() is asked at the end of the pass, before the launches, whether
+        that still holds (nothing else joined the pass).  Ignored under data parallelism (the flags are OR-ed across
+        ranks on the device there) and unless every flagged participant is covered."""
+        if self.dp is not None or any(launch not in flags for launch, _ in self._flagged):
+            return
+        parts = [flags[launch] for launch, _ in self._flagged]
+        live = [t.reshape(-1) for t in parts if t is not None]
+        if not live:
+            return
+        allf = torch.cat(live)
+        n = allf.numel()
+        if self._pinned is None or self._pinned.numel() < n:
+            self._pinned = torch.empty(max(n, 1024), dtype=torch.uint8).pin_memory()
+        self._pinned[:n].copy_(allf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._early = ([None if t is None else t.numel() for t in parts], n, ev, valid)
+
     def _end(self) -> None:
         try:
+            early, self._early = self._early, None
+            if early is not None and not early[3]():
+                early = None
             flags = [launch() for launch, _ in self._flagged]
             for f in self._finish:
                 f()
+            if early is not None and early[0] != [None if t is None else t.numel() for t in flags]:
+                early = None
             if self.defer:
-                self._held = flags
+                self._held = (flags, early)
             else:
-                self._publish(flags)
+                self._publish(flags, early)
         finally:
             self._pending = False
 
@@ -99,9 +132,23 @@ class GradCoordinator:
         """The host read a deferred pass left open (no-op otherwise)."""
         held, self._held = self._held, None
         if held is not None:
-            self._publish(held)
+            self._publish(*held)
 
-    def _publish(self, flags) -> None:
+    def _publish(self, flags, early=None) -> None:
+        if early is not None and self.dp is None:
+            early[2].synchronize()  # (long past: the copy was enqueued before the backward kernels)
+            host = [bool(v) for v in self._pinned[:early[1]].tolist()]
+            if self.check_early:
+                dev_host = torch.cat([t.reshape(-1) for t in flags if t is not None]).bool().tolist()
+                if dev_host != host:
+                    raise RuntimeError(f"GradCoordinator: early flags differ from the launches' flags: {host} vs {dev_host}")
+            self.early_used += 1
+            off = 0
+            for (_, publish), t in zip(self._flagged, flags):
+                if t is not None:
+                    publish(host[off:off + t.numel()])
+                    off += t.numel()
+            return
         extra = self.extra_params() if (self.dp is not None and self.extra_params is not None) else []
         parts = [t.reshape(-1) for t in flags if t is not None]
         if extra:
@@ -128,7 +175,7 @@ class GradCoordinator:
         gradients).  Called at a known boundary -- the start of a train_step / LoopEngine.reset():
         no pass can be in flight there, so a set flag is a stale one.  Returns True if it was."""
         stale, self._pending = self._pending, False
-        self._held = None
+        self._held = self._early = None
         return stale
 
 

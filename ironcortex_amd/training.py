@@ -245,6 +245,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     optimizer.step()
     if cfg.profile and cfg.profile_every_n_steps > 0 and step % cfg.profile_every_n_steps == 0:
         model.report_profile()
+    model.engine.prefetch_open()
     vals = torch.stack(scalars[:9] + [grad_norm.float().reshape(())] + scalars[9:]).tolist()  # one host sync for all metrics
     model.engine.resolve_open()  # (device-steered loops: their host-side record, now that the step has been waited for)
     keys = ("ff", "rtd", "denoise", "critic", "verify", "E_pos", "E_neg", "rtd_acc", "denoise_acc", "grad_norm",

@@ -21,3 +21,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _check_early_flags():
+    """Every backward pass of the suite that takes the early-flags path (GradCoordinator.offer_early) also reads the
+    flags its weight-gradient launches raise and fails on any difference."""
+    from ironcortex_amd.hip import ops
+
+    ops.GradCoordinator.check_early = True
+    yield

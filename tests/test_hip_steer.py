@@ -44,6 +44,7 @@ def run_steps(name, steer, n_steps=2, sharpen=0.0):
             state = {k: getattr(model.bank, k).clone() for k in ("num", "den", "pred", "dt", "var", "radius", "surprise")}
             out.append((met, grads, state, model.work.slots.clone(), float(model.gate.value_bias)))
         counters = dict(model.engine.counters)
+        counters["early_flags"] = model._coord.early_used
         with torch.no_grad():
             loop = model.reasoning_loop_batch(tokens.to(DEV), cfg.K_inner, focus.to(DEV))
         return out, counters, loop, model.counters["inner_steps"]
@@ -70,6 +71,9 @@ def test_steered_train_steps_equal_host_steered(name):
     a, ca, la, na = run_steps(name, True)
     b, cb, lb, nb = run_steps(name, False)
     assert ca.get("steered", 0) >= 2 and cb.get("steered", 0) == 0
+    # the steered backward hands the touched flags over before it runs (GradCoordinator.offer_early; conftest makes every
+    # such pass compare them with the flags the weight-gradient launches raise); the factorized tapes are not covered
+    assert ca["early_flags"] == (0 if name == "factorized" else 2) and cb["early_flags"] == 0
     assert_same(a, b)
     assert na == nb
     for x, y in zip(la[:3], lb[:3]):  # the no-grad batch call: H, masks, logits
