@@ -1063,7 +1063,8 @@ class LoopEngine:
     def _drop_graph(self) -> None:
         gr, self._graph = self._graph, None
         if gr is not None:
-            lib().ic_graph_destroy(gr["exec"])
+            for ex in gr["exec"]:
+                lib().ic_graph_destroy(ex)
 
     def steer_usable(self, dev, K_inner: int) -> bool:
         """Can the loops of a reasoning_loop_batch call run with the outer-iteration decisions taken on the
@@ -1094,7 +1095,7 @@ class LoopEngine:
         self._sbufs = sb
         return sb
 
-    def run_steered(self, K_inner: int, sensors: torch.Tensor, fo_all: torch.Tensor, aux_all):
+    def run_steered(self, K_inner: int, sensors: torch.Tensor, fo_all: torch.Tensor, aux_all, second=None):
         """Strict-sequential reasoning loops of a whole batch (reference model.py:462-503 over :329-460) with NO
         host wait inside: what the host decided between two outer iterations in _drive -- winner order, the
         winner's critic value, uncertainty, burst, halting (model.py:371-392,440-452) -- is decided by
@@ -1103,6 +1104,11 @@ class LoopEngine:
         an iteration behind a loop that halted is a pass-through (empty gate mask, state copied).  The loops
         run one after the other on one stream, sample j from the region state / workspace sample j-1 left
         behind: the reference's schedule, bit-identical to the host-steered path (tests/test_hip_steer.py).
+
+        second (optional): the inputs above cover only the first N1 loops of the batch; the launches of those are
+        queued, THEN second() is called for (sensors, fo_all, aux_all) of the other N - N1 loops and theirs are queued:
+        the host work that produces them (train_step: the corrupted sequences and their token mixer pass) runs while
+        the device is busy with the first loops.  Same launches in the same order either way.
 
         Call between begin_batch() and the use of the results.  sensors [N,d]; fo_all [N,C] uint8; aux_all
         [N,C,4] or None.  Returns (H [N,R,d] as ONE autograd node over `sensors` when grad is enabled,
@@ -1114,7 +1120,8 @@ class LoopEngine:
         bt = self._batch
         chunk, base, KC, N = bt["chunk"], bt["base"], bt["n_max"], bt["n_loops"]
         C, K = 2, int(K_inner)
-        assert KC == K * C and N == sensors.shape[0]
+        N1 = int(sensors.shape[0])
+        assert KC == K * C and (N == N1 if second is None else 0 < N1 < N)
         grad = torch.is_grad_enabled()
         Z = base - 1  # the slot before the first loop: the bank's state (begin_batch), H = 0, mask = 0, the workspace
         f, CP, CS = chunk.fields, chunk.ptr, chunk.stride
@@ -1126,10 +1133,10 @@ class LoopEngine:
             f["H"][Z].zero_()
             f["mask"][Z].zero_()
             f["slots"][Z].copy_(m.work.slots.detach())
-            sb["sens"].copy_(sensors.detach())
-            sb["fo"].copy_(fo_all)
+            sb["sens"][:N1].copy_(sensors.detach())
+            sb["fo"][:N1].copy_(fo_all)
             if aux_all is not None:
-                sb["aux"].copy_(aux_all)
+                sb["aux"][:N1].copy_(aux_all)
         ebias = router._cached_bias(m.reg_coords)  # (outside no_grad: requires_grad says whether the bias is trained)
         with torch.no_grad():
             sb["ebias"][:E].copy_(ebias.detach().reshape(-1))
@@ -1166,7 +1173,7 @@ class LoopEngine:
         prec, afd, rt_, use_pred = rspec.precision, bank.afd, bank.rt, bank.use_pred
         denom = float(max(1, cfg.K_inner - 1))
         dp_ = lambda ts: tuple(t.data_ptr() for t in ts if torch.is_tensor(t))
-        key = (tuple(CP.values()), base, N, K, R, d, E, flags, kw_k, kw_temp, cfg.k_active, cfg.K_inner, hs["key"],
+        key = (tuple(CP.values()), base, N, N1, K, R, d, E, flags, kw_k, kw_temp, cfg.k_active, cfg.K_inner, hs["key"],
                tuple(HP.values()), dp_(tables.values()), dp_(sb.values()), dp_(gate._tables(dev)), dp_(rP.values()),
                dp_(bP.values()), m.norm_in.weight.data_ptr(), gate.gain_ema.data_ptr(), gate.homeo.data_ptr(),
                bank.last_dir.data_ptr(), bank.last_norm.data_ptr(), (gate.w1, gate.w2, gate.w3, gate.w4, gate.w5, gate.w6),
@@ -1257,12 +1264,14 @@ class LoopEngine:
             cW, cb, cx, ccols = crit.weight.data_ptr(), crit.bias.data_ptr(), HP["c_h"], int(crit.weight.shape[1])
             la_ref = ctypes.byref(la)
 
-            def launch_all(st) -> None:
-                """Every launch of the batch on stream st: the first control block, then loop after loop."""
-                la.mode, la.ctl_next = ENUMS["IC_STEER_INIT"], ctl_p
-                rc = L.ic_loop_steer(la_ref, st)
-                if rc:
-                    check(rc, "ic_loop_steer")
+            def launch_all(st, j0=0, j1=N) -> None:
+                """Every launch of loops j0 .. j1-1 on stream st: (the first control block,) then loop after loop."""
+                if j0 == 0:
+                    la.crit_x, la.crit_cols = None, 0
+                    la.mode, la.ctl_next = ENUMS["IC_STEER_INIT"], ctl_p
+                    rc = L.ic_loop_steer(la_ref, st)
+                    if rc:
+                        check(rc, "ic_loop_steer")
                 la.crit_x, la.crit_cols = cx, ccols
                 STEP, LAST = ENUMS["IC_STEER_STEP"], ENUMS["IC_STEER_LAST"]
                 ga_ref, ra_ref, fa_ref, ha_ref = ctypes.byref(ga), ctypes.byref(ra), ctypes.byref(fa), ctypes.byref(ha)
@@ -1271,8 +1280,8 @@ class LoopEngine:
                                                                              L.ic_gemv_multi, L.ic_verify_score, L.ic_loop_steer)
                 Hm = CP["H"] + motor * d * 4
                 HS = CS["H"]
-                g = 0
-                for j in range(N):
+                g = j0 * K
+                for j in range(j0, j1):
                     ax = aux_p + j * (C * 16)
                     ver[0].x2 = ax
                     pairs_[0][0].x2 = ax
@@ -1317,12 +1326,28 @@ class LoopEngine:
 
             return launch_all
 
+        def second_inputs():
+            """The other loops' inputs (second()), into the static buffers behind the first loops' launches."""
+            s2, fo2, aux2 = second()
+            assert s2.shape[0] == N - N1
+            with torch.no_grad():
+                sb["sens"][N1:].copy_(s2.detach())
+                sb["fo"][N1:].copy_(fo2)
+                if aux2 is not None:
+                    sb["aux"][N1:].copy_(aux2)
+            return s2
+
+        parts = [(0, N)] if second is None else [(0, N1), (N1, N)]
         use_graph = GRAPH and not hip_mod.PROF_ON
         gr = self._graph
+        sensors2 = None
         if use_graph and gr is not None and gr["key"] == key:
-            rc = L.ic_graph_launch(gr["exec"], st)  # the same launch sequence as last step: one call
-            if rc:
-                check(rc, "ic_graph_launch")
+            for i, ex in enumerate(gr["exec"]):  # the same launch sequence as last step: one call (per part)
+                if i:
+                    sensors2 = second_inputs()
+                rc = L.ic_graph_launch(ex, st)
+                if rc:
+                    check(rc, "ic_graph_launch")
         elif use_graph:
             # capture the sequence once (on a stream of its own: the default stream cannot be captured), then replay it
             self._drop_graph()
@@ -1330,25 +1355,43 @@ class LoopEngine:
             cs = self._cap_stream
             if cs is None or cs.device != dev:
                 cs = self._cap_stream = torch.cuda.Stream(dev)
-            ex, nn = ctypes.c_void_p(), ctypes.c_int32(0)
-            with torch.cuda.stream(cs):
-                h = stream_handle()
-                rc = L.ic_graph_begin(h)
-                if rc:
-                    check(rc, "ic_graph_begin")
-                try:
-                    launch_all(h)
-                finally:
-                    rc = L.ic_graph_end(h, ctypes.byref(ex), ctypes.byref(nn))
-                if rc:
-                    check(rc, "ic_graph_end")
-            self._graph = {"key": key, "exec": ex, "nodes": nn.value}
+            execs, nodes = [], 0
+            try:
+                for j0, j1 in parts:
+                    ex, nn = ctypes.c_void_p(), ctypes.c_int32(0)
+                    with torch.cuda.stream(cs):
+                        h = stream_handle()
+                        rc = L.ic_graph_begin(h)
+                        if rc:
+                            check(rc, "ic_graph_begin")
+                        try:
+                            launch_all(h, j0, j1)
+                        finally:
+                            rc = L.ic_graph_end(h, ctypes.byref(ex), ctypes.byref(nn))
+                        if rc:
+                            check(rc, "ic_graph_end")
+                    execs.append(ex)
+                    nodes += nn.value
+            except Exception:
+                for ex in execs:
+                    L.ic_graph_destroy(ex)
+                raise
+            self._graph = {"key": key, "exec": execs, "nodes": nodes}
             self.counters["graph_captures"] = self.counters.get("graph_captures", 0) + 1
-            rc = L.ic_graph_launch(ex, st)
-            if rc:
-                check(rc, "ic_graph_launch")
+            for i, ex in enumerate(execs):
+                if i:
+                    sensors2 = second_inputs()
+                rc = L.ic_graph_launch(ex, st)
+                if rc:
+                    check(rc, "ic_graph_launch")
         else:
-            build()(st)
+            launch_all = build()
+            for i, (j0, j1) in enumerate(parts):
+                if i:
+                    sensors2 = second_inputs()
+                launch_all(st, j0, j1)
+        if sensors2 is not None:
+            sensors = torch.cat([sensors, sensors2], 0)
 
         # ---- results, gathered on the device through the loops' records: nothing here waits for the GPU
         with torch.no_grad():

@@ -453,16 +453,46 @@ class CortexReasoner(FastAttrs, nn.Module):
         cat = lambda l: l[0] if len(l) == 1 else torch.cat(l, 0)
         return cat(H_l), cat(M_l).bool(), cat(L_l), T_l, en.detach(), A
 
-    def reasoning_loop_batch(self, tokens_batch: torch.Tensor, K_inner: int, focus_batch: torch.Tensor):
+    def _loop_inputs(self, batched, focus_batch: torch.Tensor, N: int, dev):
+        """Per-loop inputs of the engine that do not depend on the loops' results: focus-any flags [N,C] and the
+        verifier's auxiliary rows [N,C,4] (or None)."""
+        nb_ = 1 if self.cfg.train_deterministic_inner_loop else max(1, self.cfg.B_br)
+        if focus_batch.numel() > 0:
+            fo_all = focus_batch.reshape(N, -1).any(1, keepdim=True).to(torch.uint8).repeat(1, nb_)
+        else:
+            fo_all = torch.ones(N, nb_, dtype=torch.uint8, device=dev)
+        aux_all = None
+        if self.verify is not None and getattr(self.verify, "aux_dim", 0) > 0:
+            aux_all = torch.zeros(N, nb_, 4, device=dev)
+            aux_all[:, :, 0] = batched[1].detach().reshape(N, 1)
+            if batched[2] is not None:
+                aux_all[:, :, 2] = batched[2].detach().reshape(N, 1).to(dev)
+        return fo_all, aux_all
+
+    def reasoning_loop_batch(self, tokens_batch: torch.Tensor, K_inner: int, focus_batch: torch.Tensor, second=None):
         """Sequential over the batch, region fast-weight state carried from one sample to the
-        next (detached), exactly as the reference (model.py:462-503)."""
+        next (detached), exactly as the reference (model.py:462-503).
+
+        second (optional, train_step): tokens_batch / focus_batch are only the FIRST part of the batch; second() returns
+        (tokens, focus) of the rest.  Where the loops run device-steered (LoopEngine.run_steered) it is called after the
+        first part's loops have been queued, so that the host work behind it overlaps with them; otherwise right away.
+        Results are those of the one call on the concatenated batch."""
         dev = tokens_batch.device
         H_l, M_l, L_l, T_l, E_l, A_l = [], [], [], [], [], []
+        eng = self.engine
+        if second is not None:
+            N1 = tokens_batch.shape[0]
+            split = (N1 > 1 and tokens_batch.is_cuda and not self.cfg.ff_dropout and not self.cfg.profile
+                     and self.stream_mode == "strict" and eng.steer_usable(dev, K_inner)
+                     and ((torch.is_grad_enabled() and self._logits_detached) or not torch.is_grad_enabled())
+                     and eng.usable(self.zeros_state(dev)[0], not self._logits_detached))
+            if not split:
+                t2, f2 = second()
+                tokens_batch, focus_batch, second = torch.cat([tokens_batch, t2], 0), torch.cat([focus_batch, f2], 0), None
         N = tokens_batch.shape[0]
         batched = None
         if N > 1 and tokens_batch.is_cuda and not self.cfg.ff_dropout and not self.cfg.profile:
             batched = self.sensor_vectors_batch(tokens_batch, focus_batch)  # the loops only differ in region state
-        eng = self.engine
         if self.stream_mode not in ("strict", "multi"):
             raise ValueError(f"stream_mode={self.stream_mode!r} (need 'strict' or 'multi')")
         if self.stream_mode == "multi" and batched is not None and eng.lockstep_usable(dev, N):
@@ -474,23 +504,15 @@ class CortexReasoner(FastAttrs, nn.Module):
             # so the engine records them in one block and differentiates them as ONE node
             one_node = (batched is not None and torch.is_grad_enabled() and self._logits_detached
                         and eng.usable(H_zero, False))
+            N_all = N if second is None else 2 * N  # (a split batch: the second part has as many loops as the first)
             if one_node:
-                eng.begin_batch(N, K_inner * (1 if self.cfg.train_deterministic_inner_loop else max(1, self.cfg.B_br)), dev)
+                eng.begin_batch(N_all, K_inner * (1 if self.cfg.train_deterministic_inner_loop else max(1, self.cfg.B_br)), dev)
             recorded = []
             fo_all = aux_all = None
             if batched is not None and eng.usable(H_zero, not self._logits_detached):
                 # per-loop inputs of the engine that do not depend on the loops' results: one batch
                 # of ops for all N loops instead of a handful per loop (the GPU idles between loops)
-                nb_ = 1 if self.cfg.train_deterministic_inner_loop else max(1, self.cfg.B_br)
-                if focus_batch.numel() > 0:
-                    fo_all = focus_batch.reshape(N, -1).any(1, keepdim=True).to(torch.uint8).repeat(1, nb_)
-                else:
-                    fo_all = torch.ones(N, nb_, dtype=torch.uint8, device=dev)
-                if self.verify is not None and getattr(self.verify, "aux_dim", 0) > 0:
-                    aux_all = torch.zeros(N, nb_, 4, device=dev)
-                    aux_all[:, :, 0] = batched[1].detach().reshape(N, 1)
-                    if batched[2] is not None:
-                        aux_all[:, :, 2] = batched[2].detach().reshape(N, 1).to(dev)
+                fo_all, aux_all = self._loop_inputs(batched, focus_batch, N, dev)
             # rows of the per-batch tensors: one unbind each instead of an indexing op per loop
             steer = fo_all is not None and eng.steer_usable(dev, K_inner) and (one_node or not torch.is_grad_enabled())
             if steer:
@@ -498,18 +520,35 @@ class CortexReasoner(FastAttrs, nn.Module):
                 self.detach_state()
                 if not one_node:  # no-grad call: nothing is kept from earlier loops
                     eng.reset()
-                    eng.begin_batch(N, K_inner * max(1, self.cfg.B_br), dev)
+                    eng.begin_batch(N_all, K_inner * max(1, self.cfg.B_br), dev)
+                rest = []
+
+                def second_inputs():
+                    t2, f2 = second()
+                    if t2.shape[0] != N:
+                        raise ValueError(f"reasoning_loop_batch: second() returned {t2.shape[0]} sequences, the first part has {N}")
+                    b2 = self.sensor_vectors_batch(t2, f2)
+                    rest.append(b2)
+                    return (b2[0],) + self._loop_inputs(b2, f2, N, dev)
+
                 self.router.begin_loop()
                 try:
-                    H, mk, lg, tr = eng.run_steered(K_inner, batched[0], fo_all, aux_all)
+                    H, mk, lg, tr = eng.run_steered(K_inner, batched[0], fo_all, aux_all,
+                                                    second=second_inputs if second is not None else None)
                 finally:
                     self.router.end_loop()
                 en, ent = batched[1], batched[2]
+                if rest:
+                    en = torch.cat([en, rest[0][1]], 0)
+                    ent = torch.cat([ent, rest[0][2]], 0) if ent is not None else None
+                    N = N_all
                 self.local_mix.last_energy = en[-1]
                 if ent is not None:
                     self.local_mix.attn.last_attn_entropy = ent[-1]
                 A = ent.detach().to(dev) if ent is not None else torch.zeros(N, device=dev)
                 return H, mk.bool(), lg, tr, en.detach(), A
+            if second is not None:
+                raise RuntimeError("reasoning_loop_batch: a split batch reached the host-steered path (split predicate out of step)")
             rows = lambda t: t.unbind(0) if t is not None else None
             fo_r, aux_r = rows(fo_all), rows(aux_all)
             sv_r, en_r, ent_r = (rows(batched[0]), rows(batched[1]), rows(batched[2])) if batched is not None else (None,) * 3

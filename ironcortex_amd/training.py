@@ -4,6 +4,7 @@ by batched device ops; the update order is the reference's: backward -> grad nor
 edge nudges -> homeostasis -> optimizer.step."""
 from __future__ import annotations
 
+import os
 import random
 import weakref
 from dataclasses import dataclass
@@ -29,18 +30,28 @@ class LossWeights:
     facet: float = 1e-3
 
 
-def make_negatives(clean_tokens: torch.Tensor, V: int):
+def make_negatives(clean_tokens: torch.Tensor, V: int, host: torch.Tensor = None, keep_host: bool = False):
     """Corrupt every sequence (training.py:70-89).  Random draws happen on the CPU generator in
-    the reference's order; only the results travel to the device."""
+    the reference's order; only the results travel to the device (keep_host: they stay on the host for the caller to
+    send; host: the caller's host copy of clean_tokens)."""
     dev = clean_tokens.device
-    host = clean_tokens.cpu()
+    host = clean_tokens.cpu() if host is None else host
     neg, focus, targets, masks, real = [], [], [], [], []
     for b in range(host.shape[0]):
         mode = random.choices(["RTD", "SPAN", "BLOCK"], weights=[0.5, 0.3, 0.2])[0]
         x_neg, is_real, fm, d_t, d_m = corrupt(host[b], V, mode)
         neg.append(x_neg); focus.append(fm); targets.append(d_t); masks.append(d_m)
         real.append(bool(is_real.all()))
+    if keep_host:
+        return (torch.stack(neg), torch.stack(focus), torch.stack(targets), torch.stack(masks), real)
     return (torch.stack(neg).to(dev), torch.stack(focus).to(dev), torch.stack(targets), torch.stack(masks), real)
+
+
+# IC_SPLIT=1: the corrupted half of a step's batch is drawn and mixed while the device runs the clean half's loops
+# (reasoning_loop_batch(second=...)).  Off by default: measured on the 10m bench config (same box, 30 steps, twice each)
+# 13.56 / 13.61 ms per step with it against 13.39 / 13.38 without -- the loops start 0.4 ms earlier, but the second
+# token-mixer pass sits between the two halves of the loops (0.25 ms) and its backward is a second set of launches (0.3 ms).
+SPLIT = os.environ.get("IC_SPLIT", "0") == "1"
 
 
 _MODULES = weakref.WeakKeyDictionary()  # model -> tuple of its modules (the tree is fixed after construction)
@@ -85,7 +96,6 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     model.detach_state()
     cfg = model.cfg
     B, T = clean_tokens.shape
-    optimizer.zero_grad()
     step = getattr(model, "_train_step", 0) + 1
     model._train_step = step
     for reg in model.regions:
@@ -95,30 +105,46 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         warm = min(1.0, step / cfg.surprise_lambda_schedule) if cfg.surprise_lambda_schedule > 0 else 1.0
         lam_s = cfg.surprise_lambda * warm
     model._lambda_s = lam_s
-
-    neg_tokens, focus_neg, d_targets, d_masks, is_real = make_negatives(clean_tokens, model.V)
-    tokens_all = torch.cat([clean_tokens, neg_tokens], dim=0)
-    focus_all = torch.cat([torch.zeros_like(focus_neg, dtype=torch.bool), focus_neg], dim=0)
-    # every host->device copy of the step happens HERE, before the loops are enqueued: a copy from pageable memory waits
-    # for the stream, and one issued after the loops would hold the host until they finish (8 ms in which the loss ops,
-    # the whole backward and the optimizer step could have been enqueued behind them)
-    rtd_target = (~torch.tensor(is_real, device=device)).long()
-    d_rows = [b for b in range(B) if bool(d_masks[b].any())]  # host tensors: no device sync
-    if d_rows:
-        d_first = [int(d_masks[b].nonzero(as_tuple=False)[0].item()) for b in d_rows]
-        d_pack = torch.stack([torch.stack([d_targets[b][i] for b, i in zip(d_rows, d_first)]).long(), torch.tensor(d_rows)]).to(device)
     zero = torch.zeros((), device=device)
+    host_tokens = clean_tokens.cpu()  # (before anything is queued: the corruptions below are drawn on the host)
+    neg = {}
+
+    def negatives():
+        """The corrupted sequences and every other host -> device copy of the step.  With the device-steered loops this
+        runs AFTER the loops of the clean sequences have been queued (reasoning_loop_batch(second=...)), so the host
+        work overlaps with them; the copies therefore go through pinned memory and do not wait for the stream (a copy
+        from pageable memory does, and one issued behind the loops would hold the host until they finish)."""
+        optimizer.zero_grad()
+        neg_tokens, focus_neg, d_targets, d_masks, is_real = make_negatives(clean_tokens, model.V, host_tokens, keep_host=SPLIT)
+        up = (lambda t: t.pin_memory().to(device, non_blocking=True)) if clean_tokens.is_cuda else (lambda t: t.to(device))
+        neg["tokens"], neg["focus"] = (neg_tokens, focus_neg) if neg_tokens.device == clean_tokens.device else (up(neg_tokens), up(focus_neg))
+        neg["rtd_target"] = up(~torch.tensor(is_real)).long()
+        rows_ = [b for b in range(B) if bool(d_masks[b].any())]
+        neg["d_rows"] = rows_
+        if rows_:
+            first = [int(d_masks[b].nonzero(as_tuple=False)[0].item()) for b in rows_]
+            neg["d_pack"] = up(torch.stack([torch.stack([d_targets[b][i] for b, i in zip(rows_, first)]).long(), torch.tensor(rows_)]))
+        return neg["tokens"], neg["focus"]
+
     # no loss below back-propagates through the inner-step logits / workspace (training.py:120-231):
     # the loops may run on the LoopEngine (one autograd node per loop)
     model.engine.new_step()
     model._logits_detached = True
     model.router.hold_bias = True  # every loop of this step feeds the one backward pass below
     try:
-        H_all, reg_all, logits_all, _tr, energy_all, entropy_all = model.reasoning_loop_batch(tokens_all, cfg.K_inner, focus_all)
+        if SPLIT:
+            focus_pos = torch.zeros(B, T, dtype=torch.bool, device=clean_tokens.device)
+            H_all, reg_all, logits_all, _tr, energy_all, entropy_all = model.reasoning_loop_batch(clean_tokens, cfg.K_inner, focus_pos, second=negatives)
+        else:
+            neg_tokens, focus_neg = negatives()
+            tokens_all = torch.cat([clean_tokens, neg_tokens], dim=0)
+            focus_all = torch.cat([torch.zeros_like(focus_neg, dtype=torch.bool), focus_neg], dim=0)
+            H_all, reg_all, logits_all, _tr, energy_all, entropy_all = model.reasoning_loop_batch(tokens_all, cfg.K_inner, focus_all)
     finally:
         model._logits_detached = False
         model.router.hold_bias = False
         model.router._bias_cache = None
+    rtd_target, d_rows, d_pack = neg["rtd_target"], neg["d_rows"], neg.get("d_pack")
     H_pos, H_neg = H_all[:B], H_all[B:]
     mask_p, mask_n = reg_all[:B], reg_all[B:]
     logits_pos, logits_neg = logits_all[:B], logits_all[B:]

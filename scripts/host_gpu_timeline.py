@@ -7,10 +7,14 @@ import ironcortex_amd as ic
 from ironcortex_amd import engine as E, training as T
 from bench import make_config
 dev = torch.device("cuda:0")
-cfg = make_config(sys.argv[1] if len(sys.argv) > 1 else "10m")
+MULTI = "--multi" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+cfg = make_config(argv[0] if argv else "10m")
 torch.manual_seed(0); random.seed(0)
 m = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg).to(dev)
 opt = torch.optim.AdamW(m.parameters(), lr=1e-3, fused=True)
+if MULTI:
+    m.stream_mode = "multi"
 toks = torch.randint(0, 255, (8, 256), device=dev)
 marks = []
 def mark(name):
@@ -24,6 +28,7 @@ def wrap(obj, attr, name):
 wrap(T, "make_negatives", "make_negatives")
 wrap(m, "sensor_vectors_batch", "mixer")
 wrap(m.engine, "run_steered", "run_steered")
+wrap(m.engine, "run_lockstep", "run_lockstep")
 wrap(m.engine, "backward_batch", "backward_batch")
 wrap(m._coord, "_end", "coord_end")
 wrap(m._coord, "publish", "publish")

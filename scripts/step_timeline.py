@@ -40,3 +40,33 @@ for cur in step[last_steer + 1:] + [rows[hi]]:
         print(f"  {1e-3 * g:8.1f} us at +{1e-6 * (prev[1] - t0):7.3f} ms  after {prev[2]}  before {cur[2]}")
     prev = cur
 print(f"sum of those gaps: {1e-6 * tot:.3f} ms")
+
+# ---- the loops' chain: per position inside one outer iteration (kernels between two k_loop_steer), mean duration and
+# mean gap to the kernel before, over the iterations of this step that have the most common length
+loops = step[:last_steer + 1]
+cuts = [i for i, r in enumerate(loops) if "k_loop_steer" in r[2]]
+its = [loops[a + 1:b + 1] for a, b in zip(cuts[:-1], cuts[1:])]
+prevs = [loops[a] for a in cuts[:-1]]
+from collections import Counter
+L = Counter(len(it) for it in its).most_common(1)[0][0]
+sel = [(p, it) for p, it in zip(prevs, its) if len(it) == L]
+print(f"\nloop chain: {len(its)} iterations, {len(sel)} of {L} kernels; per position: mean duration, mean gap before")
+tot_d = tot_g = 0.0
+for pos in range(L):
+    ds = [it[pos][1] - it[pos][0] for _, it in sel]
+    gs = [it[pos][0] - (it[pos - 1][1] if pos else p[1]) for p, it in sel]
+    md, mg = sum(ds) / len(ds) / 1e3, sum(gs) / len(gs) / 1e3
+    tot_d += md
+    tot_g += mg
+    print(f"  {sel[0][1][pos][2]:44s} {md:7.2f} us  gap {mg:6.2f} us")
+print(f"  per iteration: kernels {tot_d:.2f} us + gaps {tot_g:.2f} us = {tot_d + tot_g:.2f} us")
+
+# ---- what the GPU runs after the loops (losses, backward, optimizer, the next step's prologue): summed per kernel name
+from collections import defaultdict
+agg = defaultdict(lambda: [0, 0])
+for s_, e_, n_ in step[last_steer + 1:]:
+    agg[n_][0] += 1
+    agg[n_][1] += e_ - s_
+print("\nafter the loops, by kernel (launches, total us):")
+for n_, (c_, t_) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+    print(f"  {n_:44s} {c_:5d} {t_ / 1e3:9.1f}")

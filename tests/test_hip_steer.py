@@ -21,9 +21,10 @@ def build(cfg, sd):
     return model.to(DEV)
 
 
-def run_steps(name, steer, n_steps=2, sharpen=0.0):
+def run_steps(name, steer, n_steps=2, sharpen=0.0, split=False):
     import ironcortex_amd as ic
     from ironcortex_amd import engine as E
+    from ironcortex_amd import training as T
     gold, cfg, sd, tokens, focus = load_case(name)
     model = build(cfg, sd)
     if sharpen:  # confident token heads: u_mean < 0.05, so should_halt fires at k = max(1, K_inner // 2)
@@ -34,8 +35,11 @@ def run_steps(name, steer, n_steps=2, sharpen=0.0):
                 h.weight.mul_(sharpen)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     seed_train()
-    old = E.STEER
+    old, old_split = E.STEER, T.SPLIT
     E.STEER = steer
+    # split=False: the token mixer sees the whole 2B batch in one call on both paths (train_step's split prologue gives
+    # the steered path two calls of B rows: the same values, but the mixer's weight gradients summed in two parts)
+    T.SPLIT = split
     try:
         out = []
         for _ in range(n_steps):
@@ -49,7 +53,7 @@ def run_steps(name, steer, n_steps=2, sharpen=0.0):
             loop = model.reasoning_loop_batch(tokens.to(DEV), cfg.K_inner, focus.to(DEV))
         return out, counters, loop, model.counters["inner_steps"]
     finally:
-        E.STEER = old
+        E.STEER, T.SPLIT = old, old_split
 
 
 def assert_same(a, b):
@@ -112,3 +116,27 @@ def test_steered_loops_that_halt_early():
     assert_same(a, b)
     for x, y in zip(la[:3], lb[:3]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("name", ["default", "bench10m"])
+def test_split_prologue_equals_one_batch(name):
+    """train_step's split prologue (the clean sequences' loops queued first, the corrupted sequences drawn and mixed while
+    they run; training.SPLIT) against the one-batch order: the same launches on the same values.  Only the token
+    mixer's weight gradients are summed in two parts instead of one GEMM over 2B rows, hence a tolerance on the
+    gradients (1e-5 relative to the largest entry) instead of equality, and of 2e-6 on the first step's metrics."""
+    a, ca, la, na = run_steps(name, True, split=True)
+    b, cb, lb, nb = run_steps(name, True, split=False)
+    assert ca["steered"] == cb["steered"] and na == nb and ca["early_flags"] == cb["early_flags"] == 2
+    (ma, ga, sa, wa, va), (mb, gb, sb_, wb, vb) = a[0], b[0]
+    for key in ma:  # (the mixer's per-row statistics move by an ulp with the number of rows in the call)
+        assert abs(ma[key] - mb[key]) <= (1e-5 if key == "grad_norm" else 2e-6) * max(1.0, abs(mb[key])), (key, ma[key], mb[key])
+    for k in ga:
+        assert (ga[k] is None) == (gb[k] is None), k
+        if ga[k] is not None:
+            tol = 1e-5 * float(gb[k].abs().max()) + 1e-9
+            assert float((ga[k] - gb[k]).abs().max()) <= tol, (k, float((ga[k] - gb[k]).abs().max()), tol)
+    for k in sa:
+        assert torch.allclose(sa[k].float(), sb_[k].float(), rtol=1e-5, atol=1e-7), k
+    assert torch.allclose(wa, wb, rtol=1e-5, atol=1e-7) and abs(va - vb) <= 1e-6 * max(1.0, abs(vb))
+    for key in a[1][0]:  # second step: behind one optimizer update of slightly different gradients
+        assert abs(a[1][0][key] - b[1][0][key]) <= 2e-3 * max(1.0, abs(b[1][0][key])), (key, a[1][0][key], b[1][0][key])
