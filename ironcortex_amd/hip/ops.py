@@ -63,6 +63,7 @@ class GradCoordinator:
         self._flagged: List[tuple] = []  # (launch() -> Optional[uint8 tensor], publish(list of bool))
         self.dp = None
         self.extra_params: Optional[Callable[[], list]] = None
+        self.after_launch: Optional[Callable[[], None]] = None  # (data parallel: start the arenas' all-reduces)
         # defer (train_step sets it around its backward): the end of the pass launches the deferred work but leaves the
         # one host read of the flags to an explicit publish(), so that the caller can enqueue more work in between
         self.defer = False
@@ -119,6 +120,8 @@ class GradCoordinator:
             flags = [launch() for launch, _ in self._flagged]
             for f in self._finish:
                 f()
+            if self.after_launch is not None:
+                self.after_launch()
             if early is not None and early[0] != [None if t is None else t.numel() for t in flags]:
                 early = None
             if self.defer:

@@ -14,6 +14,7 @@ Region fast-weight state stays rank-local (it is not checkpointed state).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -21,13 +22,18 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, group: Optional["dist.ProcessGroup"] = None, bucket_mb: int = 64):
+    def __init__(self, group: Optional["dist.ProcessGroup"] = None, bucket_mb: int = 64, overlap: bool = True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_elems = bucket_mb * (1 << 20) // 4
+        # overlap: the arenas' all-reduces start (asynchronously, on the backend's own stream) at the end of the
+        # backward pass, as soon as the deferred weight-gradient launches are queued -- they run beside the Hebbian /
+        # homeostasis work, the flag exchange and the host side of publishing the gradients; sync_grads() only waits
+        self.overlap = overlap and os.environ.get("IC_DP_OVERLAP", "1") != "0"
+        self._inflight = None
 
     # ------------------------------------------------------------------ small helpers
     def mean(self, t: torch.Tensor) -> torch.Tensor:
@@ -81,11 +87,22 @@ class DataParallel:
         sync_grads() runs and needs no host read of its own."""
         coord = model._coord
         coord.dp = self
+        self._inflight = None  # (a pass that raised leaves nothing behind for the next one)
         coord.extra_params = lambda: model.grad_layout()[1]
+        coord.after_launch = (lambda: self.start_arena_reduce(model)) if (self.overlap and hasattr(model, "grad_layout")) else None
 
     @staticmethod
     def detach(model) -> None:
         model._coord.dp = None
+        model._coord.after_launch = None
+
+    def start_arena_reduce(self, model) -> None:
+        """End of the backward pass (GradCoordinator, after every deferred launch and per-pass reduction has been
+        queued: nothing writes the gradient arenas afterwards): start their all-reduces without waiting for them.
+        Same collectives in the same order on every rank (the arenas exist on all ranks or on none)."""
+        arenas, _ = model.grad_layout()
+        self._inflight = [(fp.gflat, dist.all_reduce(fp.gflat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                          for fp in arenas if fp.gflat is not None and fp.gflat.numel() > 0]
 
     def sync_grads(self, model) -> None:
         """Average the gradients over ranks.  The hot-path gradients (region bank, router: > 90 % of the
@@ -94,10 +111,16 @@ class DataParallel:
         Needs attach(model) before the backward pass (train_step does both)."""
         if hasattr(model, "grad_layout"):
             arenas, extra = model.grad_layout()
-            for fp in arenas:
-                if fp.gflat is not None and fp.gflat.numel() > 0:
-                    dist.all_reduce(fp.gflat, op=dist.ReduceOp.SUM, group=self.group)
-                    fp.gflat.div_(self.world)
+            inflight, self._inflight = self._inflight, None
+            if inflight is not None:  # started at the end of the backward pass (overlap)
+                for g, work in inflight:
+                    work.wait()
+                    g.div_(self.world)
+            else:
+                for fp in arenas:
+                    if fp.gflat is not None and fp.gflat.numel() > 0:
+                        dist.all_reduce(fp.gflat, op=dist.ReduceOp.SUM, group=self.group)
+                        fp.gflat.div_(self.world)
             live = [p for p in extra if p.grad is not None]  # rank-consistent (GradCoordinator._end)
             self._reduce_packed(live)
             return

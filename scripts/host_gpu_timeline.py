@@ -33,6 +33,22 @@ wrap(m.engine, "backward_batch", "backward_batch")
 wrap(m._coord, "_end", "coord_end")
 wrap(m._coord, "publish", "publish")
 wrap(opt, "step", "opt.step")
+if "--fine" in sys.argv:  # finer host-side markers inside the prologue
+    wrap(m, "detach_state", "detach_state")
+    wrap(m.engine, "new_step", "new_step")
+    wrap(m.engine, "begin_batch", "begin_batch")
+    wrap(m, "_loop_inputs", "loop_inputs")
+    wrap(m.router, "_cached_bias", "cached_bias")
+    wrap(m.engine, "_heads_setup", "heads_setup")
+    wrap(m.engine, "_steer_bufs", "steer_bufs")
+    wrap(m.router, "_edge_tables", "edge_tables")
+    wrap(m.embed, "forward", "embed")
+    wrap(m.local_mix, "forward", "local_mix")
+    from ironcortex_amd.hip import lib
+    L = lib()
+    class _W:  # (ctypes functions cannot be wrapped by setattr on the CDLL for cached attribute lookups: patch the engine's view)
+        pass
+
 wrap(opt, "zero_grad", "zero_grad")
 wrap(m, "finalize_grads", "finalize_grads")
 ob = torch.Tensor.backward

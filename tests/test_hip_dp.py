@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, q, mode="strict"):
+def _rank_main(rank, world, port, q, mode="strict", overlap=True):
     try:
         import faulthandler
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,7 +59,7 @@ def _rank_main(rank, world, port, q, mode="strict"):
         g1 = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m1.named_parameters()}
         mark("single-rank step done")
         # ---- data-parallel run
-        dp = DataParallel()
+        dp = DataParallel(overlap=overlap)
         m2 = build()
         dp.broadcast_module(m2)
         opt = torch.optim.AdamW(m2.parameters(), lr=1e-3)
@@ -68,8 +68,13 @@ def _rank_main(rank, world, port, q, mode="strict"):
         step = opt.step
         opt.step = lambda *a, **k: (captured.update({n: (None if p.grad is None else p.grad.detach().clone())
                                                      for n, p in m2.named_parameters()}), step(*a, **k))[1]
+        started = []
+        if overlap:
+            sar = dp.start_arena_reduce
+            dp.start_arena_reduce = lambda mdl: (started.append(1), sar(mdl))[1]
         out = ic.train_step(m2, opt, shard, ic.LossWeights(), dev, dp=dp)
         assert captured and out["grad_norm"] > 0
+        assert len(started) == (1 if overlap else 0) and dp._inflight is None
         mark("dp step done")
         # ---- mean of the single-rank gradients through the group: ONE packed all-reduce (+ one of the flags)
         p1 = dict(m1.named_parameters())
@@ -116,13 +121,15 @@ def _rank_main(rank, world, port, q, mode="strict"):
         q.put((rank, "fail", traceback.format_exc()[-3000:]))
 
 
-@pytest.mark.parametrize("mode", ["strict", "multi"])
-def test_dp2_train_step_on_one_gpu_over_gloo(mode):
+@pytest.mark.parametrize("mode,overlap", [("strict", True), ("strict", False), ("multi", True)])
+def test_dp2_train_step_on_one_gpu_over_gloo(mode, overlap):
+    """overlap: the arenas' all-reduces started at the end of the backward pass (asynchronously) instead of inside
+    sync_grads -- same collectives, same results."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, mode)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, mode, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = []

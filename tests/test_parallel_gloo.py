@@ -112,6 +112,7 @@ def _worker_arena(rank, world, port, q):
             f()
         m._coord._pending = True
         m._coord._end()  # what the autograd engine calls at the end of a backward pass
+        assert dp._inflight is not None and len(dp._inflight) == 1  # the arena's all-reduce is already on its way (overlap)
         dp.detach(m)
         none_before = (b.grad is None, c.grad is None, lin.bias.grad is None)
         dp.sync_grads(m)
