@@ -335,11 +335,16 @@ class LoopEngine:
             return
         m = self.model
         b = m.bank
-        for k in ("num", "den", "dt", "var", "surprise", "pred", "radius", "radius_var"):
-            setattr(b, k, getattr(b, k).clone())
+        names = ("num", "den", "dt", "var", "surprise", "pred", "radius", "radius_var")
+        src = [getattr(b, k) for k in names] + [m.work.slots] + ([m.router._last_wgt] if m.router._last_wgt is not None else [])
+        with torch.no_grad():
+            dst = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in src]
+            torch._foreach_copy_(dst, src)  # (one multi-tensor launch per dtype instead of ten clones)
+        for k, t in zip(names, dst):
+            setattr(b, k, t)
+        m.work.slots = dst[len(names)]
         if m.router._last_wgt is not None:
-            m.router._last_wgt = m.router._last_wgt.clone()
-        m.work.slots = m.work.slots.clone()
+            m.router._last_wgt = dst[len(names) + 1]
         self._state_in_arena = False
 
     # ------------------------------------------------------------------ storage
@@ -1129,17 +1134,15 @@ class LoopEngine:
         self.counters["steered"] = self.counters.get("steered", 0) + 1
         sb = self._steer_bufs(dev, N, K, C)
         W = ENUMS["IC_CTL_WORDS"]
-        with torch.no_grad():
-            f["H"][Z].zero_()
-            f["mask"][Z].zero_()
-            f["slots"][Z].copy_(m.work.slots.detach())
-            sb["sens"][:N1].copy_(sensors.detach())
-            sb["fo"][:N1].copy_(fo_all)
-            if aux_all is not None:
-                sb["aux"][:N1].copy_(aux_all)
         ebias = router._cached_bias(m.reg_coords)  # (outside no_grad: requires_grad says whether the bias is trained)
-        with torch.no_grad():
-            sb["ebias"][:E].copy_(ebias.detach().reshape(-1))
+        with torch.no_grad():  # (multi-tensor launches: one per dtype instead of a copy kernel per buffer)
+            torch._foreach_zero_([f["H"][Z], f["mask"][Z]])
+            dst = [f["slots"][Z], sb["sens"][:N1], sb["fo"][:N1], sb["ebias"][:E]]
+            src = [m.work.slots.detach(), sensors.detach(), fo_all, ebias.detach().reshape(-1)]
+            if aux_all is not None:
+                dst.append(sb["aux"][:N1])
+                src.append(aux_all)
+            torch._foreach_copy_(dst, src)
         hs = self._heads_setup(dev, C, lock="steer")
         ha, ver, steer, HP = hs["ha"], hs["ver"], hs["steer"], hs["P"]
         pairs_ = hs["pairs"]
@@ -2083,10 +2086,14 @@ class LoopEngine:
         f = chunk.fields
         pairs = [("num", "num_o"), ("den", "den_o"), ("dt", "dt_o"), ("var", "var_o"), ("surprise", "surprise_o"),
                  ("pred", "pred_o"), ("radius", "radius_o"), ("radius_var", "radius_var_o")]
+        dst, src = [], []
         for k, ko in pairs:  # the bank's state moves into the slot before the first loop
             if ko in f:
-                f[ko][i].copy_(getattr(bank, k).reshape(f[ko][i].shape))
+                dst.append(f[ko][i])
+                src.append(getattr(bank, k).detach().reshape(f[ko][i].shape))
                 setattr(bank, k, f[ko][i:i + 1])
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)  # (one multi-tensor launch per dtype instead of eight copies)
         self._state_in_arena = True
         self._batch = {"samples": [], "chunk": chunk, "base": i + 1, "n_max": n_max, "n_loops": n_loops}
 
