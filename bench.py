@@ -132,7 +132,16 @@ def cpu_baseline(cfg_name: str, B: int, T: int, seed: int):
     for _ in range(n):
         OM.oracle_train_step(model, opt, tokens, OM.LossWeights())
     dt = (time.perf_counter() - t0) / n
-    return {"value": B * T / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)  # the 1-thread number beside the all-core one (one more step, already warm)
+    try:
+        t0 = time.perf_counter()
+        OM.oracle_train_step(model, opt, tokens, OM.LossWeights())
+        dt1 = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads)
+    return {"value": B * T / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "one_thread": {"value": B * T / dt1, "s_per_step": dt1},
             "sample": f"2 train_steps of the full B={B},T={T} batch after 1 warm-up ({dt:.2f} s/step), "
                       f"oracle/model.py (reference-shaped per-region Python loop), torch {torch.__version__} CPU",
             "s_per_step": dt, "host_cpus": os.cpu_count()}
