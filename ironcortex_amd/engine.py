@@ -1346,7 +1346,7 @@ class LoopEngine:
         sensors2 = None
         if use_graph and gr is not None and gr["key"] == key:
             for i, ex in enumerate(gr["exec"]):  # the same launch sequence as last step: one call (per part)
-                if i:
+                if i and second is not None:
                     sensors2 = second_inputs()
                 rc = L.ic_graph_launch(ex, st)
                 if rc:
@@ -1382,7 +1382,7 @@ class LoopEngine:
             self._graph = {"key": key, "exec": execs, "nodes": nodes}
             self.counters["graph_captures"] = self.counters.get("graph_captures", 0) + 1
             for i, ex in enumerate(execs):
-                if i:
+                if i and second is not None:
                     sensors2 = second_inputs()
                 rc = L.ic_graph_launch(ex, st)
                 if rc:
@@ -1390,7 +1390,7 @@ class LoopEngine:
         else:
             launch_all = build()
             for i, (j0, j1) in enumerate(parts):
-                if i:
+                if i and second is not None:
                     sensors2 = second_inputs()
                 launch_all(st, j0, j1)
         if sensors2 is not None:
