@@ -25,6 +25,7 @@ gradients (per-step rows are summed per loop instead of accumulated step by step
 from __future__ import annotations
 
 import ctypes
+import warnings
 import os
 from typing import Dict, List, Optional, Tuple
 
@@ -179,6 +180,7 @@ class LoopEngine:
         self._events = None
         self._wsb = None
         self._graph = None       # captured launch sequence of the steered loops (run_steered)
+        self._graph_off = False  # (set when a capture failed: call-by-call launches from then on)
         self._cap_stream = None
         self.counters = {"batch_bwd": 0, "loop_bwd": 0, "lockstep": 0}  # backward passes taken all-loops-at-once / loop by loop
         model._coord.register(self._begin_pass, self._finish_pass)
@@ -1341,7 +1343,7 @@ class LoopEngine:
             return s2
 
         parts = [(0, N)] if second is None else [(0, N1), (N1, N)]
-        use_graph = GRAPH and not hip_mod.PROF_ON
+        use_graph = GRAPH and not hip_mod.PROF_ON and not self._graph_off
         gr = self._graph
         sensors2 = None
         if use_graph and gr is not None and gr["key"] == key:
@@ -1375,18 +1377,29 @@ class LoopEngine:
                             check(rc, "ic_graph_end")
                     execs.append(ex)
                     nodes += nn.value
-            except Exception:
+            except RuntimeError as exc:
+                # a capture the runtime refuses (nothing has run: captured launches only execute on replay) must not
+                # cost the step: from now on this engine launches call by call, as with IC_GRAPH=0
                 for ex in execs:
                     L.ic_graph_destroy(ex)
-                raise
-            self._graph = {"key": key, "exec": execs, "nodes": nodes}
-            self.counters["graph_captures"] = self.counters.get("graph_captures", 0) + 1
-            for i, ex in enumerate(execs):
-                if i and second is not None:
-                    sensors2 = second_inputs()
-                rc = L.ic_graph_launch(ex, st)
-                if rc:
-                    check(rc, "ic_graph_launch")
+                execs = None
+                self._graph_off = True
+                warnings.warn(f"LoopEngine: HIP graph capture failed ({exc}); launching the loops call by call from now on")
+            if execs is not None:
+                self._graph = {"key": key, "exec": execs, "nodes": nodes}
+                self.counters["graph_captures"] = self.counters.get("graph_captures", 0) + 1
+                for i, ex in enumerate(execs):
+                    if i and second is not None:
+                        sensors2 = second_inputs()
+                    rc = L.ic_graph_launch(ex, st)
+                    if rc:
+                        check(rc, "ic_graph_launch")
+            else:
+                launch_all = build()
+                for i, (j0, j1) in enumerate(parts):
+                    if i and second is not None:
+                        sensors2 = second_inputs()
+                    launch_all(st, j0, j1)
         else:
             launch_all = build()
             for i, (j0, j1) in enumerate(parts):

@@ -140,3 +140,19 @@ def test_split_prologue_equals_one_batch(name):
     assert torch.allclose(wa, wb, rtol=1e-5, atol=1e-7) and abs(va - vb) <= 1e-6 * max(1.0, abs(vb))
     for key in a[1][0]:  # second step: behind one optimizer update of slightly different gradients
         assert abs(a[1][0][key] - b[1][0][key]) <= 2e-3 * max(1.0, abs(b[1][0][key])), (key, a[1][0][key], b[1][0][key])
+
+
+def test_graph_capture_failure_falls_back_to_plain_launches(monkeypatch):
+    """A runtime that refuses the capture (here: ic_graph_begin made to fail) must not cost the step: the loops are
+    launched call by call from then on, same results."""
+    import warnings
+    from ironcortex_amd.hip import lib
+    a, ca, la, _ = run_steps("default", True)
+    L = lib()
+    monkeypatch.setattr(L, "ic_graph_begin", lambda h: -3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        b, cb, lb, _ = run_steps("default", True)
+    assert any("graph capture failed" in str(x.message) for x in w)
+    assert ca.get("graph_captures", 0) >= 1 and cb.get("graph_captures", 0) == 0 and cb["steered"] == ca["steered"]
+    assert_same(a, b)
