@@ -47,11 +47,19 @@ def make_config(name: str):
                             enable_forward_forward=True, debug_metrics_every_n_steps=2)
     if name == "default":  # reference train_tiny_shakespeare.py:59-67
         return CortexConfig(R=36, d=256, V=256, K_inner=8, B_br=2, k_active=8, max_T=512)
+    if name in ("r512", "r64"):  # BASELINE configs[2], model level: the 10M flags on a large map (not a `value` workload)
+        return CortexConfig(R=int(name[1:]), d=256, V=256, K_inner=8, B_br=2, k_active=32, max_T=512,
+                            enable_adaptive_filter_dynamics=True, enable_precision_routed_messages=True,
+                            enable_radial_tangential_updates=True, enable_afa_attention=True,
+                            enable_ff_energy_alignment=True, enable_energy_verifier=True,
+                            enable_forward_forward=True, debug_metrics_every_n_steps=2)
     raise SystemExit(f"unknown --config {name}")
 
 
 WORKLOAD = {"10m": "train_tiny_shakespeare_10m.py config (R=10,d=256,all flags on)",
-            "default": "train_tiny_shakespeare.py default config (R=36,d=256)"}
+            "default": "train_tiny_shakespeare.py default config (R=36,d=256)",
+            "r512": "configs[2] model level: 10M-script flags on R=512, k_active=32, d=256",
+            "r64": "configs[2] model level: 10M-script flags on R=64, k_active=32, d=256"}
 
 
 def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:

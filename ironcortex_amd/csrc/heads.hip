@@ -10,6 +10,10 @@
 
 namespace {
 
+// maps of up to this many regions walk all R rows where a sum over the ACTIVE regions is formed (two round trips at
+// R = 10); larger ones find the active rows by ballot first (R = 512: 64 dependent round trips became 8 + n_active / 8)
+constexpr int kSmallR = 16;
+
 constexpr int kMaxCols = 4096;  // longest input vector a GEMV stages in LDS
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -396,17 +400,42 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
   for (int j = 0; j < VPT; ++j) {
     const int v = tid + 256 * j;
     lg[j] = -INFINITY;
+    float reg = 0.f;
+    if (R > kSmallR) {
+      // large maps: only the rows of the regions in the mean, found 64 at a time by a ballot (every lane of the wave
+      // takes part, also those beyond V) and added in the same (row) order -- the rows skipped hold zeros, so the sum
+      // is the small-map loop's bit for bit, in R/64 + n_active/8 memory round trips instead of R/8
+      for (int base = 0; base < R; base += 64) {
+        const int rr = base + (tid & 63);
+        unsigned long long bal = __ballot(rr < R && rr != a.motor_idx && a.mask[rr] != 0);
+        while (bal) {
+          float pr[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            pr[u] = 0.f;
+            if (bal) {  // wave-uniform
+              const int row = base + __ffsll((long long)bal) - 1;
+              bal &= bal - 1;
+              if (v < V) pr[u] = a.per_region[(size_t)row * V + v];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) reg += pr[u];
+        }
+      }
+    }
     if (v < V) {
       float zf[KF];
 #pragma unroll
       for (int f = 0; f < KF; ++f) zf[f] = f < Kf ? a.z[Kf + f * V + v] : 0.f;
-      float reg = 0.f;
-      for (int r0 = 0; r0 < R; r0 += 8) {  // inactive rows hold zeros: no mask test in the load chain
-        float pr[8];
+      if (R <= kSmallR) {
+        for (int r0 = 0; r0 < R; r0 += 8) {  // inactive rows hold zeros: no mask test in the load chain
+          float pr[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pr[u] = r0 + u < R ? a.per_region[(size_t)(r0 + u) * V + v] : 0.f;
+          for (int u = 0; u < 8; ++u) pr[u] = r0 + u < R ? a.per_region[(size_t)(r0 + u) * V + v] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) reg += pr[u];
+          for (int u = 0; u < 8; ++u) reg += pr[u];
+        }
       }
       float acc = 0.f;
 #pragma unroll
@@ -571,6 +600,37 @@ __device__ __forceinline__ void token_rows_multi(const ic_heads_args& a0, int la
 
 // mean of the active rows of H (same arithmetic as k_steer_select): one workgroup per stream
 __device__ __forceinline__ void ws_mean_rows(const ic_heads_args& a) {
+  if (a.R > kSmallR) {
+    // large maps: the active rows found 64 at a time by a ballot, 8 of them in flight, added in row order: the same
+    // sums as below (which walks all R rows), in R/64 + n_active/8 round trips instead of R/8
+    const int lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < a.d + 255 - (a.d + 255) % 256; c += 256) {  // (whole waves: the ballots need every lane)
+      float s = 0.f;
+      int cnt = 0;
+      for (int base = 0; base < a.R; base += 64) {
+        unsigned long long bal = __ballot(base + lane < a.R && a.mask[base + lane] != 0);
+        cnt += __popcll(bal);
+        while (bal) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v[u] = 0.f;
+            if (bal) {  // wave-uniform
+              const int row = base + __ffsll((long long)bal) - 1;
+              bal &= bal - 1;
+              if (c < a.d) v[u] = a.H[(size_t)row * a.d + c];
+            } else {
+              v[u] = -0.f;  // (x + -0.f == x for every x: the padding of the last batch changes nothing)
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += v[u];
+        }
+      }
+      if (c < a.d) a.ws_mean[c] = s / fmaxf((float)cnt, 1.0f);
+    }
+    return;
+  }
   float n_on = 0.f;
   for (int r = 0; r < a.R; ++r) n_on += a.mask[r] ? 1.0f : 0.0f;
   const float den = fmaxf(n_on, 1.0f);
@@ -611,13 +671,46 @@ __device__ __forceinline__ void gemv_on_ws_mean(const ic_heads_args& a, const ic
     xr[i] = 0.f;
   }
   const float b0 = g.b ? g.b[row0] : 0.f, b1 = (g.b && two) ? g.b[row0 + 1] : 0.f;
+  constexpr int UB = NX <= 4 ? 8 : (NX <= 8 ? 4 : 2);
   float n_on = 0.f;
-  for (int r = 0; r < a.R; ++r) n_on += a.mask[r] ? 1.0f : 0.0f;
+  if (a.R > kSmallR) {  // large maps: active rows by ballot, as in ws_mean_rows (same sums)
+    int cnt = 0;
+    for (int base = 0; base < a.R; base += 64) {
+      unsigned long long bal = __ballot(base + lane < a.R && a.mask[base + lane] != 0);
+      cnt += __popcll(bal);
+      while (bal) {
+        float v[UB][NX];
+        bool on[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          on[u] = bal != 0;  // wave-uniform
+          int row = 0;
+          if (bal) {
+            row = base + __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            const int c = lane + 64 * i;
+            v[u][i] = (on[u] && c < cols) ? a.H[(size_t)row * a.d + c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (on[u]) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xr[i] += v[u][i];
+          }
+      }
+    }
+    n_on = (float)cnt;
+  } else {
+    for (int r = 0; r < a.R; ++r) n_on += a.mask[r] ? 1.0f : 0.0f;
+  }
   const float den = fmaxf(n_on, 1.0f);
   // rows are requested UB at a time whether active or not (L2 hits), then added in row order if
   // active: one memory round trip per UB rows instead of two per active row
-  constexpr int UB = NX <= 4 ? 8 : (NX <= 8 ? 4 : 2);
-  for (int r0 = 0; r0 < a.R; r0 += UB) {
+  for (int r0 = 0; r0 < (a.R > kSmallR ? 0 : a.R); r0 += UB) {
     float v[UB][NX];
     bool on[UB];
 #pragma unroll

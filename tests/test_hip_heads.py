@@ -23,8 +23,22 @@ def close(a, b, rtol=2e-5, atol=2e-6, what=""):
 
 
 def build_pair(name):
+    """name of a fixture case, or "<case>@R": that case's configuration on a map of R regions with seeded fresh weights
+    (no reference fixture: product and oracle share the weights) -- maps above 16 regions take the heads kernels'
+    ballot-driven walks over the active rows instead of the all-rows loops."""
+    import dataclasses
     import ironcortex_amd as ic
     from oracle import model as OM
+    if "@" in name:
+        base, R = name.split("@")
+        _g, cfg, _sd, _t, _f = load_case(base)
+        cfg = dataclasses.replace(cfg, R=int(R))
+        torch.manual_seed(1234)
+        prod = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
+        sd = {k: v.detach().clone() for k, v in prod.state_dict().items()}
+        orc = OM.build(cfg)
+        orc.load_state_dict(sd)
+        return cfg, prod.to(DEV), orc
     gold, cfg, sd, tokens, focus = load_case(name)
     prod = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)
     prod.load_state_dict(sd)
@@ -47,7 +61,8 @@ def step_inputs(cfg, seed, n_active):
     return H, H_par, mask, slots, surprise
 
 
-@pytest.mark.parametrize("name,n_active", [("default", 4), ("allflags", 10), ("allflags", 2)])
+@pytest.mark.parametrize("name,n_active", [("default", 4), ("allflags", 10), ("allflags", 2), ("allflags@40", 13),
+                                           ("allflags@150", 40), ("allflags@150", 2)])
 def test_heads_fwd_vs_oracle(name, n_active):
     from ironcortex_amd import hip
     from ironcortex_amd.utils import context_logprob
@@ -95,9 +110,10 @@ def test_heads_fwd_vs_oracle(name, n_active):
     close(prod.work.slots, orc.work.slots, what="general-path slots")
 
 
-def test_steer_chain_and_verify_score_vs_oracle():
+@pytest.mark.parametrize("name", ["allflags", "allflags@40"])
+def test_steer_chain_and_verify_score_vs_oracle(name):
     from ironcortex_amd import hip
-    cfg, prod, orc = build_pair("allflags")
+    cfg, prod, orc = build_pair(name)
     R, d, V, motor = cfg.R, cfg.d, cfg.V, cfg.R - 1
     dev = torch.device(DEV)
     hs = prod.engine._heads_setup(dev)
@@ -167,14 +183,15 @@ def test_gemv_chain_rejects_bad_descriptors():
     assert rc == hip.ENUMS["IC_EINVAL"] and b"ic_gemv_chain" in hip.lib().ic_last_error()
 
 
-def test_strided_streams_equal_separate_calls():
+@pytest.mark.parametrize("name", ["allflags", "allflags@40", "allflags@150"])
+def test_strided_streams_equal_separate_calls(name):
     """The batched-branch launches: gate + router with the two streams' inputs in REVERSED slot
     order (negative stream stride) must equal two single-stream calls; same for the batched heads
     and verifier chain."""
     import ironcortex_amd as ic
     from ironcortex_amd import hip
     from ironcortex_amd.hip import ops
-    cfg, prod, _ = build_pair("allflags")
+    cfg, prod, _ = build_pair(name)
     R, d, V = cfg.R, cfg.d, cfg.V
     dev = torch.device(DEV)
     L, st = hip.lib(), hip.stream_handle()
