@@ -61,20 +61,25 @@ __global__ __launch_bounds__(256) void k_gate_scores(ic_gate_args a) {
 }
 
 // One workgroup per stream.
+constexpr int kGateLdsNbr = 6144;  // a hex map of 1024 regions
 __global__ __launch_bounds__(256) void k_gate_select(ic_gate_args a) {
-  __shared__ float sc[1024];
+  __shared__ __align__(16) float sc[1024];
   __shared__ int order[1024];
   __shared__ uint8_t supp[1024];
+  // the adjacency in LDS while it fits (hex maps: <= 6 neighbours per region)
+  __shared__ uint16_t l_off[1025];
+  __shared__ uint16_t l_nbr[kGateLdsNbr];
   const int s = blockIdx.x;
   for (int i = threadIdx.x; i < a.R; i += blockDim.x) sc[i] = a.scores[s * a.R + i];
   __syncthreads();
-  gate_select_body(a, s, sc, order, supp);
+  if (a.nbr_off[a.R] <= kGateLdsNbr) gate_select_body(a, s, sc, order, supp, l_off, l_nbr);  // (workgroup-uniform)
+  else gate_select_body(a, s, sc, order, supp);
 }
 
 // Scores and selection in ONE launch for small region counts (body: ic_gate.h).
 template <int DCH>
 __global__ __launch_bounds__(256) void k_gate_fused(ic_gate_args a) {
-  __shared__ float sc[1024];
+  __shared__ __align__(16) float sc[1024];
   __shared__ int order[1024];
   __shared__ uint8_t supp[1024];
   gate_fused_body<DCH>(a, blockIdx.x, sc, order, supp);

@@ -15,24 +15,130 @@ __device__ __forceinline__ float gate_t6(const ic_gate_args& a, int s) { return 
 
 // Stable descending rank by counting, then the greedy suppression walk on one lane (R <= 1024,
 // the walk stops after k selections).  sc[] holds the stream's scores; all threads call.
-__device__ __forceinline__ void gate_select_body(const ic_gate_args& a, int s, const float* sc, int* order,
-                                                 uint8_t* supp) {
-  const int R = a.R;
+// l_off / l_nbr (optional, LDS: R + 1 and nbr_off[R] entries): the adjacency staged by the whole workgroup for the
+// walk on large maps (below).  nullptr: the walk reads it from memory, one lane (small maps: a handful of selections).
+// sc must be 16-byte aligned with room up to the next multiple of 4 (the ranking reads it four scores at a time).
+__device__ __forceinline__ void gate_select_body(const ic_gate_args& a, int s, float* sc, int* order,
+                                                 uint8_t* supp, uint16_t* l_off = nullptr, uint16_t* l_nbr = nullptr) {
+  const int R = a.R, R4 = (R + 3) & ~3;
   for (int i = threadIdx.x; i < R; i += blockDim.x) {
     supp[i] = 0;
     a.mask[s * R + i] = 0;
   }
-  __syncthreads();
+  if (threadIdx.x < R4 - R) sc[R + threadIdx.x] = -INFINITY;  // (never above, never equal to a score)
+  int big_deg = 0;
+  if (l_off) {
+    for (int i = threadIdx.x; i <= R; i += blockDim.x) {
+      l_off[i] = (uint16_t)a.nbr_off[i];
+      if (i < R) big_deg |= a.nbr_off[i + 1] - a.nbr_off[i] > 8;
+    }
+    const int n = a.nbr_off[R];
+    for (int q = threadIdx.x; q < n; q += blockDim.x) l_nbr[q] = (uint16_t)a.nbr[q];
+  }
+  big_deg = __syncthreads_or(big_deg);
+  if (l_off && R > 64) {
+    // Large maps: the same total order (score descending, index ascending) from a bitonic sorting network over
+    // (score, index) pairs in LDS, padded to a power of two with (-inf, index >= R) pairs, which sort behind every
+    // region.  R^2 comparisons on the one CU this workgroup owns were 29 us of a launch at R = 512 and 106 us at
+    // R = 1024 (4 cycles per wave instruction); the network is R/2 log^2 R compare-exchanges.
+    int n = 64;
+    while (n < R) n <<= 1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      if (i >= R) sc[i] = -INFINITY;
+      order[i] = i;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= n; k2 <<= 1) {
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < n / 2; t += blockDim.x) {
+          const int i = (t / j) * 2 * j + (t % j), l = i + j;
+          const float ka = sc[i], kb = sc[l];
+          const int ia = order[i], ib = order[l];
+          const bool a_first = (ka > kb) || (ka == kb && ia < ib);
+          const bool want_a_first = (i & k2) == 0;
+          if (a_first != want_a_first) {
+            sc[i] = kb; sc[l] = ka;
+            order[i] = ib; order[l] = ia;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  } else
+  // stable descending rank by counting (four scores per LDS read, four reads in flight)
   for (int i = threadIdx.x; i < R; i += blockDim.x) {
     const float v = sc[i];
+    const float4* s4 = reinterpret_cast<const float4*>(sc);
     int rank = 0;
-    for (int j = 0; j < R; ++j) {
-      const float u = sc[j];
-      rank += (u > v) || (u == v && j < i);
+#pragma unroll 4
+    for (int j4 = 0; j4 < R4 / 4; ++j4) {
+      const float4 u = s4[j4];
+      const int j = 4 * j4;
+      rank += (u.x > v) || (u.x == v && j < i);
+      rank += (u.y > v) || (u.y == v && j + 1 < i);
+      rank += (u.z > v) || (u.z == v && j + 2 < i);
+      rank += (u.w > v) || (u.w == v && j + 3 < i);
     }
     order[rank] = i;
   }
   __syncthreads();
+  if (l_off && !big_deg) {
+    // The walk of utils.py:115-123 by ONE WAVE, 64 candidates of the order at a time: every lane holds its candidate
+    // and that candidate's neighbours (<= 8, packed in registers); a ballot of the candidates no earlier selection has
+    // suppressed; the first of them is selected, its neighbour list is broadcast from its lane, the lanes whose candidate
+    // is that region or one of the neighbours drop out of the ballot, nine lanes mark them for the chunks to come.
+    // Same selections in the same order as the one-lane walk below, no memory round trip per selection
+    // (R = 512, 97 selections: 50 us of a launch -> ~5).
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    uint8_t* mask = a.mask + s * R;
+    const int kt = a.k_total_s ? a.k_total_s[s] : a.k_total;
+    if (kt == IC_GATE_OFF) return;
+    int k = kt > 0 ? kt : 0;
+    if (a.force_io) {
+      if (lane == 0) {
+        mask[a.sensor_idx] = 1;
+        mask[a.motor_idx] = 1;
+      }
+      k = k - 2 > 0 ? k - 2 : 0;
+    }
+    int count = 0;
+    for (int p0 = 0; p0 < R; p0 += 64) {
+      const int il = p0 + lane < R ? order[p0 + lane] : -1;
+      unsigned int nb[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      if (il >= 0) {
+        const int o0 = l_off[il], deg = l_off[il + 1] - o0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned int v = q < deg ? (unsigned int)l_nbr[o0 + q] : 0xFFFFu;
+          nb[q >> 1] = (q & 1) ? ((nb[q >> 1] & 0xFFFFu) | (v << 16)) : ((nb[q >> 1] & 0xFFFF0000u) | v);
+        }
+      }
+      unsigned long long alive = __ballot(il >= 0 && supp[il] == 0);
+      while (alive) {
+        const int l0 = __ffsll((long long)alive) - 1;
+        const int i = __builtin_amdgcn_readlane(il, l0);
+        if (lane == 0) mask[i] = 1;
+        ++count;
+        if (count >= k) return;  // utils.py:118-120: tested after the append
+        unsigned int sel[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sel[w] = (unsigned int)__builtin_amdgcn_readlane((int)nb[w], l0);
+        if (lane < 8) {  // nine lanes mark the region and its neighbours ...
+          const unsigned int w = lane < 2 ? sel[0] : (lane < 4 ? sel[1] : (lane < 6 ? sel[2] : sel[3]));
+          const int v = (int)((w >> (16 * (lane & 1))) & 0xFFFFu);
+          if (v != 0xFFFF) supp[v] = 1;
+        } else if (lane == 8) {
+          supp[i] = 1;
+        }
+        // ... and every lane looks its own candidate up again (LDS operations of one wave complete in order): one
+        // LDS round trip and ~25 instructions per selection; comparing against the eight broadcast neighbours in
+        // registers was ~80 instructions of a single wave, 0.3 us
+        alive &= __ballot(il >= 0 && supp[il] == 0);
+      }
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
     uint8_t* mask = a.mask + s * R;
     const int kt = a.k_total_s ? a.k_total_s[s] : a.k_total;

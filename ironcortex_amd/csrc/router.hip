@@ -191,7 +191,7 @@ template <int DCH, bool PRECISION>
 __global__ __launch_bounds__(256) void k_front(ic_router_args a, ic_gate_args g) {
   if ((int)blockIdx.y < g.S) {
     if (blockIdx.x != 0 || blockIdx.z != 0) return;
-    __shared__ float sc[1024];
+    __shared__ __align__(16) float sc[1024];
     __shared__ int order[1024];
     __shared__ uint8_t supp[1024];
     gate_fused_body<DCH>(g, blockIdx.y, sc, order, supp);

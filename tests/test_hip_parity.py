@@ -382,14 +382,16 @@ def test_gate_select_vs_oracle_random():
     from ironcortex_amd.gate import Gate
     from ironcortex_amd.wiring import hex_neighbors
     from oracle import hotpath as O
-    for R in (4, 10, 36, 128, 512):
+    # (above 64 regions ic_gate_select ranks with a sorting network padded to a power of two and walks 64 candidates at a
+    # time: sizes on both sides of the chunk and padding boundaries)
+    for R in (4, 10, 36, 64, 65, 100, 128, 300, 512, 1000):
         nb = hex_neighbors(R)
         gate = Gate(R, nb, {"sensor": 0, "motor": R - 1}).to(DEV)
         for trial in range(4):
             sc = gi.det(900 + R + trial, R)
             if trial % 2:
                 sc = torch.round(sc * 2) / 2  # many ties
-            for k_active, burst in ((0, 0), (2, 0), (3, 1), (8, 4), (32, 64)):
+            for k_active, burst in ((0, 0), (2, 0), (3, 1), (8, 4), (32, 64), (32, R // 8), (200, 0)):
                 ref = O.gate_select(sc, k_active, burst, nb, 0, R - 1, stable=True)
                 got = gate.select_k(sc.to(DEV), k_active, burst)
                 assert torch.equal(got.cpu(), ref), (R, trial, k_active, burst)
