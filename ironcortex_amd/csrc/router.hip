@@ -1247,8 +1247,12 @@ extern "C" int ic_router_wgrad(const ic_wgrad_edge_args* a, ic_stream_t stream) 
   IC_REQUIRE(a->tape_g && a->tape_H && a->tape_eact && a->visited && a->gW && a->touched,
              "ic_router_wgrad: NULL pointer");
   IC_REQUIRE(a->which == 2 || (a->src && a->widx), "ic_router_wgrad: NULL edge table");
-  if (a->which != 2 && a->nW != a->E) {  // shared matrices (by_direction): one deterministic MFMA GEMM per matrix
-    IC_REQUIRE(a->nW >= 1 && a->nW <= 64 && a->E <= 4096, "ic_router_wgrad: shared matrices need nW in [1,64] and E <= 4096 (nW=%d, E=%d)",
+  // shared matrices (by_direction): one deterministic MFMA GEMM per matrix.  A caller that passes the pair-list
+  // workspace asks for the same GEMM for one matrix per edge too (dW_e = sum over the tape's slots g (x) h: with hundreds
+  // of slots per edge -- the LoopEngine's pass over all loops of a train_step -- that is a [d,T] x [T,d] product per edge,
+  // which the row-slice kernel below re-reads from L2 once per 8 rows: 88 us against ~20 at R=10, 1.1 ms at R=512)
+  if (a->which != 2 && (a->nW != a->E || a->pair_ws != nullptr)) {
+    IC_REQUIRE(a->nW >= 1 && a->nW <= 8192 && a->E <= 4096, "ic_router_wgrad: the GEMM path needs nW in [1,8192] and E <= 4096 (nW=%d, E=%d)",
                a->nW, a->E);
     int rc = ic_wgrad_shared_launch(a, (hipStream_t)stream);
     if (rc) return rc;

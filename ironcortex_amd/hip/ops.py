@@ -240,6 +240,10 @@ class Tape:
         self.pos = 0
 
 
+# IC_WGRAD_GEMM=0: the deferred per-edge / per-region weight gradients always through the row-slice kernels (A/B timing)
+WGRAD_GEMM = os.environ.get("IC_WGRAD_GEMM", "1") != "0"
+WGRAD_GEMM_MIN_TS = 64  # (stream, slot) pairs on the tapes from which the pair-list GEMM is used
+
 # rows of W per workgroup in the forward GEMVs (0 = library default); a tuning knob for the sweeps
 ROWS_FWD = int(os.environ.get("IC_ROWS_FWD", "0"))
 
@@ -409,8 +413,37 @@ class RegionPhaseFn(torch.autograd.Function):
                 out.get("gpred"), out.get("gradius"), out.get("gradius_var"), None)
 
 
+_REGION_WGRAD_TABLES: Dict[tuple, Dict[str, torch.Tensor]] = {}
+_IOTA: Dict[tuple, torch.Tensor] = {}
+
+
 def region_wgrad(tape: Tape, S: int, R: int, d: int, gW: torch.Tensor, touched: torch.Tensor) -> None:
     if tape.pos == 0:
+        return
+    TS = tape.pos * S
+    if WGRAD_GEMM and WGRAD_GEMM_MIN_TS <= TS <= 4096 and d % 32 == 0 and 4 * R <= 4096:
+        # Many tape slots (the LoopEngine's pass over all loops of a train_step): dW[r,j] = sum g (x) op is a
+        # [d,TS] x [TS,d] product per matrix -- the router's pair-list GEMM on the matrix cores with the region tapes
+        # read as 4R "edges" (edge 4r+j: gradient rows g[.,r,j,:], operand row of region r, matrix 4r+j).  The r/k/v
+        # matrices take the x tape, the output projection the o tape: two launches, the other matrices' lists empty.
+        dev = gW.device
+        key = (R, dev)
+        t = _REGION_WGRAD_TABLES.get(key)
+        if t is None:
+            e = torch.arange(4 * R, dtype=torch.int32, device=dev)
+            neg = torch.full_like(e, -1)
+            t = _REGION_WGRAD_TABLES[key] = {"src": (e // 4).contiguous(), "rkv": torch.where(e % 4 < 3, e, neg).contiguous(),
+                                             "o": torch.where(e % 4 == 3, e, neg).contiguous()}
+        act4 = tape.buf["mask"][:tape.pos].reshape(TS, R, 1).expand(TS, R, 4).contiguous()  # activity per (pair, pseudo edge)
+        t4 = torch.zeros(4 * R, dtype=torch.uint8, device=dev)
+        n = (2 * 4 * R + TS * 4 * R + 63) // 64 * 64
+        ws = torch.empty(n, dtype=torch.int32, device=dev)
+        for widx, op in ((t["rkv"], tape.buf["x"]), (t["o"], tape.buf["o"])):
+            a = new("ic_wgrad_edge_args", T=tape.pos, S=S, R=R, d=d, E=4 * R, nW=4 * R, which=0, dst_off=t["src"], src=t["src"],
+                    widx=widx, tape_g=tape.buf["g"], tape_H=op, tape_eact=act4, visited=tape.visited, gW=gW, touched=t4)
+            a.pair_ws, a.pair_ws_len = ptr(ws), n
+            _call("ic_router_wgrad", a)
+        touched.copy_(torch.maximum(touched, t4.view(R, 4).amax(1)))
         return
     a = new("ic_wgrad_region_args", T=tape.pos, S=S, R=R, d=d, tape_g=tape.buf["g"], tape_x=tape.buf["x"],
             tape_o=tape.buf["o"], mask=tape.buf["mask"], visited=tape.visited, gW=gW, touched=touched)
@@ -528,14 +561,31 @@ def router_wgrad(tape: Tape, spec: RouterSpec, tables: Dict[str, torch.Tensor], 
     if tape.pos == 0 or spec.E == 0:
         return
     gname = ("gmsg", "gkey", "gq")[which]
+    TS = tape.pos * S
     a = new("ic_wgrad_edge_args", T=tape.pos, S=S, R=spec.R, d=spec.d, E=spec.E, nW=spec.nW, which=which,
             dst_off=tables["dst_off"], src=tables["src"], widx=tables["widx"], tape_g=tape.buf[gname],
             tape_H=tape.buf["H"], tape_eact=tape.buf["qact" if which == 2 else "eact"], visited=tape.visited,
             gW=gW, touched=touched)
     if which != 2 and spec.nW != spec.E:  # shared matrices: workspace for the compacted list of contributing pairs
-        n = (2 * spec.nW + tape.pos * S * spec.E + 63) // 64 * 64 + 8 * spec.nW * spec.d * spec.d  # list + split-K partial tiles
+        n = (2 * spec.nW + TS * spec.E + 63) // 64 * 64 + 8 * spec.nW * spec.d * spec.d  # list + split-K partial tiles
         ws = torch.empty(n, dtype=torch.int32, device=gW.device)
         a.pair_ws, a.pair_ws_len = ptr(ws), n
+    elif WGRAD_GEMM and WGRAD_GEMM_MIN_TS <= TS <= 4096 and spec.d % 32 == 0:
+        # one matrix per edge (or per region: the queries), many tape slots: the same pair-list GEMM, a list per matrix.
+        # The queries' tape is indexed by region: identity edge tables turn it into the edge form.
+        if which == 2:
+            it = _IOTA.get((spec.R, gW.device))  # (not kept in `tables`: the graph replay keys on that dict's pointers)
+            if it is None:
+                it = _IOTA[(spec.R, gW.device)] = torch.arange(spec.R + 1, dtype=torch.int32, device=gW.device)
+            a.which, a.E, a.nW, a.dst_off, a.src, a.widx = 0, spec.R, spec.R, ptr(it), ptr(it), ptr(it)
+        n_m, n_e = (spec.R, spec.R) if which == 2 else (spec.nW, spec.E)
+        if n_e <= 4096 and n_m <= 8192:
+            n = (2 * n_m + TS * n_e + 63) // 64 * 64
+            ws = torch.empty(n, dtype=torch.int32, device=gW.device)
+            a.pair_ws, a.pair_ws_len = ptr(ws), n
+        elif which == 2:  # (too large for the list kernels: back to the region-indexed row-slice kernel)
+            a.which, a.E, a.nW = 2, spec.E, spec.nW
+            a.dst_off, a.src, a.widx = ptr(tables["dst_off"]), ptr(tables["src"]), ptr(tables["widx"])
     _call("ic_router_wgrad", a)
 
 
