@@ -105,6 +105,11 @@ def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
         "kwta_rows": st.get("rows", 0) * 3 * vec, "goodness_fwd": st.get("rows", 0) * vec, "goodness_bwd": st.get("rows", 0) * 2 * vec,
         "hebbian": st.get("e_upd", 0) * dd * 2,
     }
+    # the deferred weight gradients as pair-list GEMMs (LoopEngine passes with >= 64 tape slots): region matrices in two
+    # calls (r/k/v, o), edge matrices in one per kind (messages; + keys, queries with precision routing), each call a
+    # list kernel and a GEMM kernel under ONE kernel id -> the same bytes as the row-slice kernels, averaged per launch
+    n_calls = 2 + (3 if prec else 1)
+    table["wgrad_mfma"] = (table["wgrad_region"] + (n_calls - 2) * table["wgrad_edge"]) / (2 * n_calls)
     if st.get("fsplit"):  # >= 32 streams per launch: k_region_rkvG (weights, x row in, 3 raw rows out) + k_region_state
         table["region_rkv"] = u_f * 3 * dd + n_f * 4 * vec
         table["region_state"] = n_f * (10 + (3 if afd else 0)) * vec

@@ -287,14 +287,17 @@ typedef struct ic_wgrad_edge_args {
   const uint8_t* visited;   /* [T] */
   float* gW;                /* [nW,d,d] (which==2: [R,d,d]) accumulated in place */
   uint8_t* touched;         /* [nW] or [R] */
-  int32_t* pair_ws;         /* shared matrices only, optional: workspace of pair_ws_len >= 2*nW + T*S*E 32-bit words for the
+  int32_t* pair_ws;         /* optional (which < 2): workspace of pair_ws_len >= 2*nW + T*S*E 32-bit words for the
                                compacted list of contributing (slot, stream, edge) pairs per matrix; with it the MFMA
                                GEMM walks only those pairs.  ceil64(that) + ks*nW*d*d words (ks = 2, 4 or 8) more let
                                it split K over ks workgroups per tile (partial tiles summed in order: deterministic).
-                               NULL: the GEMM tests every pair itself. */
+                               Shared matrices (nW != E) without it: the GEMM tests every pair itself.  One matrix per
+                               edge (nW == E): passing it SELECTS the GEMM (worth it from ~64 (slot, stream) pairs on
+                               the tape; widx[e] < 0 leaves edge e out), NULL the row-slice kernel. */
   int64_t pair_ws_len;
 } ic_wgrad_edge_args;
-/* (nW != E, which < 2: shared matrices -- one deterministic MFMA GEMM per matrix, dW_k += G_k X_k^T, no float atomics) */
+/* (which < 2 and nW != E or pair_ws set: one deterministic MFMA GEMM per matrix, dW_k += G_k X_k^T, no float atomics;
+ * nW <= 8192, E <= 4096) */
 int ic_router_wgrad(const ic_wgrad_edge_args* a, ic_stream_t stream);
 
 /* ------------------------------------------------------------------ gate
