@@ -243,6 +243,7 @@ class Tape:
 # IC_WGRAD_GEMM=0: the deferred per-edge / per-region weight gradients always through the row-slice kernels (A/B timing)
 WGRAD_GEMM = os.environ.get("IC_WGRAD_GEMM", "1") != "0"
 WGRAD_GEMM_MIN_TS = 64  # (stream, slot) pairs on the tapes from which the pair-list GEMM is used
+WGRAD_GEMM_CALLS = [0]  # (tests: how many weight-gradient calls took the GEMM)
 
 # rows of W per workgroup in the forward GEMVs (0 = library default); a tuning knob for the sweeps
 ROWS_FWD = int(os.environ.get("IC_ROWS_FWD", "0"))
@@ -438,6 +439,7 @@ def region_wgrad(tape: Tape, S: int, R: int, d: int, gW: torch.Tensor, touched: 
         t4 = torch.zeros(4 * R, dtype=torch.uint8, device=dev)
         n = (2 * 4 * R + TS * 4 * R + 63) // 64 * 64
         ws = torch.empty(n, dtype=torch.int32, device=dev)
+        WGRAD_GEMM_CALLS[0] += 1
         for widx, op in ((t["rkv"], tape.buf["x"]), (t["o"], tape.buf["o"])):
             a = new("ic_wgrad_edge_args", T=tape.pos, S=S, R=R, d=d, E=4 * R, nW=4 * R, which=0, dst_off=t["src"], src=t["src"],
                     widx=widx, tape_g=tape.buf["g"], tape_H=op, tape_eact=act4, visited=tape.visited, gW=gW, touched=t4)
@@ -583,6 +585,7 @@ def router_wgrad(tape: Tape, spec: RouterSpec, tables: Dict[str, torch.Tensor], 
             n = (2 * n_m + TS * n_e + 63) // 64 * 64
             ws = torch.empty(n, dtype=torch.int32, device=gW.device)
             a.pair_ws, a.pair_ws_len = ptr(ws), n
+            WGRAD_GEMM_CALLS[0] += 1
         elif which == 2:  # (too large for the list kernels: back to the region-indexed row-slice kernel)
             a.which, a.E, a.nW = 2, spec.E, spec.nW
             a.dst_off, a.src, a.widx = ptr(tables["dst_off"]), ptr(tables["src"]), ptr(tables["widx"])

@@ -156,3 +156,28 @@ def test_graph_capture_failure_falls_back_to_plain_launches(monkeypatch):
     assert any("graph capture failed" in str(x.message) for x in w)
     assert ca.get("graph_captures", 0) >= 1 and cb.get("graph_captures", 0) == 0 and cb["steered"] == ca["steered"]
     assert_same(a, b)
+
+
+@pytest.mark.parametrize("name", ["bench10m", "r36"])
+def test_wgrad_gemm_equals_row_slice_kernels(name, monkeypatch):
+    """The deferred weight gradients of a step's loops through the pair-list MFMA GEMM (tapes of >= 64 (slot, stream)
+    pairs: region matrices as 4R pseudo edges, edge matrices, keys, queries) against the row-slice kernels on the same
+    tapes: same sums in another order -- 2e-6 of each gradient's largest entry, identical None-ness."""
+    from ironcortex_amd.hip import ops
+    n0 = ops.WGRAD_GEMM_CALLS[0]
+    a, *_ = run_steps(name, True, n_steps=1)
+    assert ops.WGRAD_GEMM_CALLS[0] >= n0 + 2, "the GEMM path was not taken"
+    monkeypatch.setattr(ops, "WGRAD_GEMM", False)
+    n1 = ops.WGRAD_GEMM_CALLS[0]
+    b, *_ = run_steps(name, True, n_steps=1)
+    assert ops.WGRAD_GEMM_CALLS[0] == n1
+    ga, gb = a[0][1], b[0][1]
+    worst = 0.0
+    for k in ga:
+        assert (ga[k] is None) == (gb[k] is None), k
+        if ga[k] is not None:
+            scale = float(gb[k].abs().max())
+            err = float((ga[k] - gb[k]).abs().max())
+            assert err <= 2e-6 * scale + 1e-12, (k, err, scale)
+            worst = max(worst, err / max(scale, 1e-30))
+    assert {k: v for k, v in a[0][0].items() if k != "grad_norm"} == {k: v for k, v in b[0][0].items() if k != "grad_norm"}
