@@ -52,6 +52,21 @@ STEER = os.environ.get("IC_STEER", "1") != "0"
 # IC_GRAPH=0: the steered loops are launched call by call every step instead of replayed as one captured HIP graph
 GRAPH = os.environ.get("IC_GRAPH", "1") != "0"
 
+def _copy_many(dst, src) -> None:
+    """dst[i].copy_(src[i]) as one multi-tensor launch per dtype (torch._foreach_copy_ only takes its fused route when
+    every tensor of the call has the same dtype; a mixed list silently becomes one copy kernel per tensor)."""
+    groups = {}
+    for d_, s_ in zip(dst, src):
+        groups.setdefault((d_.dtype, s_.dtype), ([], []))
+        groups[(d_.dtype, s_.dtype)][0].append(d_)
+        groups[(d_.dtype, s_.dtype)][1].append(s_)
+    for ds, ss in groups.values():
+        if len(ds) == 1:
+            ds[0].copy_(ss[0])
+        else:
+            torch._foreach_copy_(ds, ss)
+
+
 class StructImage:
     """Per-step images of a C argument struct.  Most pointer fields of a step's arguments are
     `base + t * stride` (step arena, tape, gradient rows); instead of ~50 ctypes attribute
@@ -341,7 +356,7 @@ class LoopEngine:
         src = [getattr(b, k) for k in names] + [m.work.slots] + ([m.router._last_wgt] if m.router._last_wgt is not None else [])
         with torch.no_grad():
             dst = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in src]
-            torch._foreach_copy_(dst, src)  # (one multi-tensor launch per dtype instead of ten clones)
+            _copy_many(dst, src)  # (one multi-tensor launch per dtype instead of ten clones)
         for k, t in zip(names, dst):
             setattr(b, k, t)
         m.work.slots = dst[len(names)]
@@ -1144,7 +1159,7 @@ class LoopEngine:
             if aux_all is not None:
                 dst.append(sb["aux"][:N1])
                 src.append(aux_all)
-            torch._foreach_copy_(dst, src)
+            _copy_many(dst, src)
         hs = self._heads_setup(dev, C, lock="steer")
         ha, ver, steer, HP = hs["ha"], hs["ver"], hs["steer"], hs["P"]
         pairs_ = hs["pairs"]
@@ -2106,7 +2121,7 @@ class LoopEngine:
                 src.append(getattr(bank, k).detach().reshape(f[ko][i].shape))
                 setattr(bank, k, f[ko][i:i + 1])
         with torch.no_grad():
-            torch._foreach_copy_(dst, src)  # (one multi-tensor launch per dtype instead of eight copies)
+            _copy_many(dst, src)  # (one multi-tensor launch per dtype instead of eight copies)
         self._state_in_arena = True
         self._batch = {"samples": [], "chunk": chunk, "base": i + 1, "n_max": n_max, "n_loops": n_loops}
 
