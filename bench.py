@@ -119,6 +119,12 @@ def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:
     return table.get(kernel, 0.0)
 
 
+# flops per (query, key) pair of the attention kernels (fp32 MFMA, dense peak 157.3 TFLOP/s): scores + probabilities x
+# values forward; both transposed products per operand backward (scripts/mixer_bench.py)
+ATTN_FLOPS = {"attn_fwd": lambda dqk, dv: 2 * (2 * dqk + dv), "attn_bwd_kv": lambda dqk, dv: 2 * (2 * dqk + 2 * dv),
+              "attn_bwd_q": lambda dqk, dv: 2 * (2 * dqk + dv)}
+
+
 def pmc_traffic(kernel: str, cfg_name: str):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
     command (profiles/r03_pmc_traffic.json; PMC collection serialises kernels, so it is a
@@ -382,6 +388,13 @@ def main():
                 table[k] = {"ms_per_step": round(ms_, 4), "launches_per_step": n_, "avg_us": round(us, 2),
                             "alg_KB_per_launch": round(abk / 1e3, 1),
                             "GBs": round(abk / (us * 1e-6) / 1e9, 1) if abk else None}
+                if k in ATTN_FLOPS:  # MFMA-bound kernels of the token mixer: flops, not bytes
+                    hd = cfg.d // 4
+                    dqk = hd if cfg.enable_afa_attention else hd + 64
+                    Ta = T + (0 if cfg.enable_afa_attention else sum(len(range(S_ // 2, T, S_)) for S_ in (128, 32)) + 8)
+                    fl = ATTN_FLOPS[k](dqk, hd) * 2 * B * 4 * Ta * Ta  # per (query, key) pair x sequences x heads x positions^2
+                    table[k].update(alg_GFLOP_per_launch=round(fl / 1e9, 3), TFLOPs=round(fl / (us * 1e-6) / 1e12, 1),
+                                    frac_of_fp32_mfma_peak=round(fl / (us * 1e-6) / 1e12 / 157.3, 3))
             out["kernels"] = table
             out["kernels_source"] = ("HIP events on every library kernel during the last warm-up step; algorithmic bytes "
                                      "from bench.algorithmic_bytes x device-counted units, or the library's launch-time count")
