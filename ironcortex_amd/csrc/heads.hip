@@ -537,11 +537,10 @@ __device__ __forceinline__ ic_heads_args heads_stream(ic_heads_args a, int s) {
 // the per-stream grid re-read the 4.7 MB of head weights 32 times from L2 (30 us); same sums per stream.
 constexpr int kHeadsSB = 8;
 template <int DCH>
-__device__ __forceinline__ void token_rows_multi(const ic_heads_args& a0, int lane, int wave, const int grp, const int xb,
-                                                 const int s0, const int s1) {
+__device__ __forceinline__ void token_rows_multi(const ic_heads_args& a0, int lane, int wave, const int grp, const int xb0,
+                                                 const int nxb, const int s0, const int s1) {
   const int d = a0.d;
   const int rows = grp == 0 ? a0.Kf + a0.Kf * a0.V : a0.V;
-  const int row0 = xb * 8 + wave * 2;
   const int r = grp - 1;
   RowFrag<DCH> xv[kHeadsSB];
   bool on[kHeadsSB];
@@ -553,47 +552,52 @@ __device__ __forceinline__ void token_rows_multi(const ic_heads_args& a0, int la
     if (s0 + u < s1) {
       const ic_heads_args a = heads_stream(a0, s0 + u);
       on[u] = grp == 0 || (r != a.motor_idx && a.mask[r] != 0);
-      if (on[u] && row0 < rows) load_row(xv[u], a.H + (size_t)(grp == 0 ? a.motor_idx : r) * d, d, lane);
+      if (on[u] && xb0 * 8 + wave * 2 < rows) load_row(xv[u], a.H + (size_t)(grp == 0 ? a.motor_idx : r) * d, d, lane);
       any |= on[u];
     }
   }
-  RowFrag<DCH> w[2];
-  float bias[2] = {0.f, 0.f};
-  zero_frag(w[0]);
-  zero_frag(w[1]);
-  if (any && row0 < rows) {
-    const float* W = grp == 0 ? a0.lm_W - (size_t)a0.Kf * d : a0.rh_W + (size_t)r * a0.V * d;  // facet row i sits at z[Kf + i]
-    const float* b = grp == 0 ? a0.lm_b - a0.Kf : a0.rh_b + (size_t)r * a0.V;
+  // maps above kSmallR regions: the combine only reads the rows of the regions in the mean, nothing to zero here
+  if (!any && a0.R > kSmallR) return;
+  for (int xb = xb0; xb < xb0 + nxb; ++xb) {
+    const int row0 = xb * 8 + wave * 2;
+    RowFrag<DCH> w[2];
+    float bias[2] = {0.f, 0.f};
+    zero_frag(w[0]);
+    zero_frag(w[1]);
+    if (any && row0 < rows) {
+      const float* W = grp == 0 ? a0.lm_W - (size_t)a0.Kf * d : a0.rh_W + (size_t)r * a0.V * d;  // facet row i sits at z[Kf + i]
+      const float* b = grp == 0 ? a0.lm_b - a0.Kf : a0.rh_b + (size_t)r * a0.V;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = row0 + i;
-      if (row < rows) {
-        const float* wr = W + (size_t)row * d;
-        const float* br = b + row;
-        if (grp == 0 && row < a0.Kf) {  // the MFS gate rows come first in z
-          wr = a0.lm_gate_W + (size_t)row * d;
-          br = a0.lm_gate_b + row;
+      for (int i = 0; i < 2; ++i) {
+        const int row = row0 + i;
+        if (row < rows) {
+          const float* wr = W + (size_t)row * d;
+          const float* br = b + row;
+          if (grp == 0 && row < a0.Kf) {  // the MFS gate rows come first in z
+            wr = a0.lm_gate_W + (size_t)row * d;
+            br = a0.lm_gate_b + row;
+          }
+          load_row(w[i], wr, d, lane);
+          bias[i] = *br;
         }
-        load_row(w[i], wr, d, lane);
-        bias[i] = *br;
       }
     }
-  }
 #pragma unroll
-  for (int u = 0; u < kHeadsSB; ++u) {
-    if (s0 + u >= s1) break;
-    const ic_heads_args a = heads_stream(a0, s0 + u);
-    if (!on[u]) {  // not part of the mean (model.py:314-317): zeros, so the combine can add all R rows
-      const int v = xb * 8 + (int)threadIdx.x;  // this block's 8 rows (threads 0..7)
-      if (threadIdx.x < 8 && v < a.V) a.per_region[(size_t)r * a.V + v] = 0.f;
-      continue;
-    }
-    if (row0 >= rows) continue;
-    float* y = grp == 0 ? a.z : a.per_region + (size_t)r * a.V;
-    const float t0 = wave_sum(dot_frag(w[0], xv[u])), t1 = wave_sum(dot_frag(w[1], xv[u]));
-    if (lane == 0) {
-      y[row0] = t0 + bias[0];
-      if (row0 + 1 < rows) y[row0 + 1] = t1 + bias[1];
+    for (int u = 0; u < kHeadsSB; ++u) {
+      if (s0 + u >= s1) break;
+      const ic_heads_args a = heads_stream(a0, s0 + u);
+      if (!on[u]) {  // not part of the mean (model.py:314-317): zeros, so the small-map combine can add all R rows
+        const int v = xb * 8 + (int)threadIdx.x;  // this block's 8 rows (threads 0..7)
+        if (threadIdx.x < 8 && v < a.V && a0.R <= kSmallR) a.per_region[(size_t)r * a.V + v] = 0.f;
+        continue;
+      }
+      if (row0 >= rows) continue;
+      float* y = grp == 0 ? a.z : a.per_region + (size_t)r * a.V;
+      const float t0 = wave_sum(dot_frag(w[0], xv[u])), t1 = wave_sum(dot_frag(w[1], xv[u]));
+      if (lane == 0) {
+        y[row0] = t0 + bias[0];
+        if (row0 + 1 < rows) y[row0 + 1] = t1 + bias[1];
+      }
     }
   }
 }
@@ -748,17 +752,19 @@ __device__ __forceinline__ void gemv_on_ws_mean(const ic_heads_args& a, const ic
 // [workspace write: ceil(n_slots/4)] [row sums of squares: ceil(R/4)] [ws_mean: 1 if asked for]
 // [a GEMV on that mean: ceil(rows/8) if asked for]
 template <int DCH>
-__global__ __launch_bounds__(256) void k_heads(ic_heads_args a0, ic_gemv_desc g0, int n_g, int sb) {
+__global__ __launch_bounds__(256) void k_heads(ic_heads_args a0, ic_gemv_desc g0, int n_g, int sb, int rp8) {
   // blockIdx.y = a batch of up to kHeadsSB streams: the head rows serve the whole batch from one read of their
   // weights, the small per-stream pieces run stream after stream
   const int S = a0.S > 1 ? a0.S : 1;
   const int s0 = blockIdx.y * sb, s1 = min(S, s0 + sb);  // sb = 1 (few streams: one workgroup row per stream) or kHeadsSB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int b = blockIdx.x;
-  const int n_tok = (a0.Kf + a0.Kf * a0.V + 7) / 8, n_rh = (a0.V + 7) / 8;
-  if (b < n_tok) return token_rows_multi<DCH>(a0, lane, wave, 0, b, s0, s1);
+  // region heads: rp8 groups of 8 rows per workgroup (1 on small maps; 8 on large ones, where a grid of R x V/8
+  // workgroups of which a few per cent find an active region was the launch: 16 384 at R = 512)
+  const int n_tok = (a0.Kf + a0.Kf * a0.V + 7) / 8, n_rh = (a0.V + 8 * rp8 - 1) / (8 * rp8);
+  if (b < n_tok) return token_rows_multi<DCH>(a0, lane, wave, 0, b, 1, s0, s1);
   b -= n_tok;
-  if (b < a0.R * n_rh) return token_rows_multi<DCH>(a0, lane, wave, 1 + b / n_rh, b % n_rh, s0, s1);
+  if (b < a0.R * n_rh) return token_rows_multi<DCH>(a0, lane, wave, 1 + b / n_rh, (b % n_rh) * rp8, rp8, s0, s1);
   b -= a0.R * n_rh;
   // the small per-stream pieces keep a workgroup of their own per stream: n_small blocks for each stream of the batch
   const int n_ws = (a0.n_slots + 3) / 4, n_sq = (a0.R + 3) / 4;
@@ -1088,7 +1094,8 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_ge
   IC_REQUIRE(S <= 64, "ic_heads_fwd: S=%d (need <= 64)", S);
   const int n_g = gm ? ic_ceil_div(gm->rows, 8) : 0;
   const int sb = S > 4 ? kHeadsSB : 1;  // (two branches of one loop: 9 us per stream row against 14 us batched)
-  const int nblk = ic_ceil_div(a->Kf + a->Kf * a->V, 8) + a->R * ic_ceil_div(a->V, 8) +
+  const int rp8 = a->R > 64 ? 8 : 1;  // 8-row groups per region-head workgroup (k_heads)
+  const int nblk = ic_ceil_div(a->Kf + a->Kf * a->V, 8) + a->R * ic_ceil_div(a->V, 8 * rp8) +
                    sb * (ic_ceil_div(a->n_slots, 4) + ic_ceil_div(a->R, 4) + (a->ws_mean ? 1 : 0) + n_g);
   ic_gemv_desc g_none = {};
   if (timed) {
@@ -1099,7 +1106,7 @@ static int heads_fwd(const ic_heads_args* a, const ic_gemv_desc* gm, const ic_ge
     IC_BYTES(IC_KID_logits_combine, 4.0 * (double)S * (a->Kf + (double)a->Kf * a->V + (double)a->R * a->V + 4.0 * a->V) + (g ? gemv_bytes(*g) : 0.0));
   }
   IC_DISPATCH_DCH(a->d, {
-    IC_MAYBE_TIMED(timed, IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, ic_ceil_div(S, sb)), dim3(256), 0, st, *a, gm ? *gm : g_none, n_g, sb));
+    IC_MAYBE_TIMED(timed, IC_KID_token_rows, st, hipLaunchKernelGGL(k_heads<DCH>, dim3(nblk, ic_ceil_div(S, sb)), dim3(256), 0, st, *a, gm ? *gm : g_none, n_g, sb, rp8));
   });
   if (g) {
     const int cols = g->n0 + g->n1 + g->n2, nb = g->nbatch > 1 ? g->nbatch : 1;
