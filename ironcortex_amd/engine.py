@@ -1117,7 +1117,7 @@ class LoopEngine:
         self._sbufs = sb
         return sb
 
-    def run_steered(self, K_inner: int, sensors: torch.Tensor, fo_all: torch.Tensor, aux_all, second=None):
+    def run_steered(self, K_inner: int, sensors: torch.Tensor, fo_all: torch.Tensor, aux_all, second=None, init=None):
         """Strict-sequential reasoning loops of a whole batch (reference model.py:462-503 over :329-460) with NO
         host wait inside: what the host decided between two outer iterations in _drive -- winner order, the
         winner's critic value, uncertainty, burst, halting (model.py:371-392,440-452) -- is decided by
@@ -1131,6 +1131,10 @@ class LoopEngine:
         queued, THEN second() is called for (sensors, fo_all, aux_all) of the other N - N1 loops and theirs are queued:
         the host work that produces them (train_step: the corrupted sequences and their token mixer pass) runs while
         the device is busy with the first loops.  Same launches in the same order either way.
+
+        init (optional, no-grad calls): (H [R,d], mask [R]) the FIRST loop starts from instead of the all-zero state
+        (generation: reasoning_loop hands each call the previous call's winner, reference generation.py:27-29); the
+        critic value of its first iteration is then computed from that state.
 
         Call between begin_batch() and the use of the results.  sensors [N,d]; fo_all [N,C] uint8; aux_all
         [N,C,4] or None.  Returns (H [N,R,d] as ONE autograd node over `sensors` when grad is enabled,
@@ -1153,9 +1157,14 @@ class LoopEngine:
         W = ENUMS["IC_CTL_WORDS"]
         ebias = router._cached_bias(m.reg_coords)  # (outside no_grad: requires_grad says whether the bias is trained)
         with torch.no_grad():  # (multi-tensor launches: one per dtype instead of a copy kernel per buffer)
-            torch._foreach_zero_([f["H"][Z], f["mask"][Z]])
             dst = [f["slots"][Z], sb["sens"][:N1], sb["fo"][:N1], sb["ebias"][:E]]
             src = [m.work.slots.detach(), sensors.detach(), fo_all, ebias.detach().reshape(-1)]
+            if init is None:
+                torch._foreach_zero_([f["H"][Z], f["mask"][Z]])
+            else:
+                assert not grad and N == 1, "run_steered: an initial state is a no-grad, single-loop feature"
+                dst += [f["H"][Z], f["mask"][Z]]
+                src += [init[0].detach().reshape(R, d), init[1].detach().to(_U8).reshape(R)]
             if aux_all is not None:
                 dst.append(sb["aux"][:N1])
                 src.append(aux_all)
@@ -1167,7 +1176,7 @@ class LoopEngine:
 
         # ---- critic value of the all-zero state (first iteration of every loop), left on the device
         pv, self._vhat0_pending = getattr(self, "_vhat0_pending", None), None
-        if pv is not None and pv[3] == dev:
+        if pv is not None and pv[3] == dev and init is None:
             # new_step() queued the chain; its result sits in the pinned score block of the host-steered set-up
             sb["vhat0"].copy_(pv[1][pv[2]:pv[2] + 1], non_blocking=True)
         else:

@@ -349,6 +349,9 @@ class CortexReasoner(FastAttrs, nn.Module):
         self.router.begin_loop()
         try:
             if self.engine.usable(H_prev, not self._logits_detached):
+                if (not torch.is_grad_enabled() and tokens.is_cuda and self.stream_mode == "strict" and not self.cfg.ff_dropout
+                        and not self.cfg.profile and self.engine.steer_usable(H_prev.device, K_inner)):
+                    return self._reasoning_loop_steered(tokens, K_inner, focus_map, reg_mask_prev, H_prev)
                 return self.engine.run(tokens, K_inner, focus_map, reg_mask_prev, H_prev)
             self._in_loop = True
             return self._reasoning_loop(tokens, K_inner, focus_map, reg_mask_prev, H_prev)
@@ -356,6 +359,23 @@ class CortexReasoner(FastAttrs, nn.Module):
             self._in_loop = False
             self._loop_cache = None
             self.router.end_loop()
+
+    def _reasoning_loop_steered(self, tokens, K_inner, focus_map, reg_mask_prev, H_prev):
+        """A single no-grad loop (generation, evaluation) on the device-steered engine: the launches of its K_inner outer
+        iterations queued back to back -- replayed as one captured graph from the second call on -- instead of one host
+        wait per iteration; same kernels, same results (LoopEngine.run_steered with the caller's initial state)."""
+        dev = H_prev.device
+        eng = self.engine
+        batched = self.sensor_vectors_batch(tokens.unsqueeze(0), focus_map.unsqueeze(0))
+        fo_all, aux_all = self._loop_inputs(batched, focus_map.unsqueeze(0), 1, dev)
+        self.detach_state()
+        eng.reset()
+        eng.begin_batch(1, K_inner * max(1, self.cfg.B_br), dev)
+        H, mk, lg, tr = eng.run_steered(K_inner, batched[0], fo_all, aux_all, init=(H_prev, reg_mask_prev))
+        self.local_mix.last_energy = batched[1][-1]
+        if batched[2] is not None:
+            self.local_mix.attn.last_attn_entropy = batched[2][-1]
+        return H[0], mk[0].bool(), lg[0], tr[0]
 
     def _reasoning_loop(self, tokens, K_inner, focus_map, reg_mask_prev, H_prev):
         dev = H_prev.device
