@@ -205,7 +205,7 @@ class IronRoPESelfAttention(nn.Module):
 
 class AdaptiveFilterAttention(FastAttrs, nn.Module):
     """Dot-product attention times exp(-alpha |lag| dt) (adaptive_filter_attention.py:8-127)."""
-    _plain_attrs = frozenset({"last_attn_entropy"})
+    _plain_attrs = frozenset({"last_attn_entropy", "_kernel_norm"})
 
     def __init__(self, d_model: int, n_head: int, dt: float = 1.0, alpha: float = 0.0, *,
                  debug_exact: bool = False, exact_threshold: int = 64):
@@ -219,8 +219,26 @@ class AdaptiveFilterAttention(FastAttrs, nn.Module):
         self.q_proj, self.k_proj = nn.Linear(d_model, d_model), nn.Linear(d_model, d_model)
         self.v_proj, self.out_proj = nn.Linear(d_model, d_model), nn.Linear(d_model, d_model)
         self.register_buffer("last_attn_energy", torch.tensor(0.0), persistent=False)
-        self.register_buffer("last_kernel_norm", torch.tensor(0.0), persistent=False)
+        self._kernel_norm = torch.tensor(0.0)  # a tensor, or (alpha at the time, T) of the last kernel call: formed on demand
         self.last_attn_entropy = torch.tensor(0.0)
+
+    @property
+    def last_kernel_norm(self) -> torch.Tensor:
+        """||exp(-alpha |i-j| dt)||_F of the last call (adaptive_filter_attention.py:73; telemetry only).  The kernel path
+        keeps (a copy of alpha, T) and forms the value when somebody asks: ten small launches per token-mixer call
+        otherwise, on the host-bound stretch of a train_step before its loops start."""
+        kn = self._kernel_norm
+        if isinstance(kn, tuple):
+            a, T = kn
+            with torch.no_grad():
+                lag = torch.arange(1, T, device=a.device, dtype=torch.float32)
+                w = torch.exp(-2.0 * a * lag * self.dt) * (T - lag)  # ||decay||_F^2 = T + 2 sum_lag (T-lag) e^(-2 a lag dt)
+                kn = self._kernel_norm = (T + 2.0 * w.sum()).sqrt()
+        return kn
+
+    @last_kernel_norm.setter
+    def last_kernel_norm(self, value) -> None:
+        self._kernel_norm = value
 
     def _attend(self, q, k, v, mask):
         if mask is None and ops.attention_fits(self.head_dim, self.head_dim):  # (heads wider than 128: [T,T] path)
@@ -232,9 +250,7 @@ class AdaptiveFilterAttention(FastAttrs, nn.Module):
         B, H, T, _ = q.shape
         out, stats = ops.attention(q * self.scale, k, v, alpha=self.alpha, lag_dt=float(self.dt), eps_log=EPS_LOG)
         with torch.no_grad():
-            lag = torch.arange(1, T, device=q.device, dtype=torch.float32)
-            w = torch.exp(-2.0 * self.alpha.detach() * lag * self.dt) * (T - lag)  # ||decay||_F^2 = T + 2 sum_lag (T-lag) e^(-2 a lag dt)
-            self.last_kernel_norm = (T + 2.0 * w.sum()).sqrt()
+            self._kernel_norm = (self.alpha.detach().clone(), T)  # (see last_kernel_norm)
             s0, s1 = stats[..., 0], stats[..., 1]
             self.last_attn_energy_b = -s0.sum(dim=(1, 2)) / float(H * T * T)
             self.last_attn_entropy_b = -s1.sum(dim=(1, 2)) / float(H * T)

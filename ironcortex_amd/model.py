@@ -228,8 +228,12 @@ class CortexReasoner(FastAttrs, nn.Module):
         N, T = tokens_batch.shape
         dev = tokens_batch.device
         tok_emb = self.embed(tokens_batch)
-        idx = torch.arange(T, device=dev, dtype=torch.float32)
-        pos = torch.stack([idx, idx / (T + EPS_DIV)], dim=-1).unsqueeze(0).expand(N, T, 2)
+        pc = getattr(self, "_pos_cache", None)
+        if pc is None or pc[0] != (T, dev):  # (positions depend on T alone: three launches per call otherwise)
+            idx = torch.arange(T, device=dev, dtype=torch.float32)
+            pc = ((T, dev), torch.stack([idx, idx / (T + EPS_DIV)], dim=-1).unsqueeze(0))
+            object.__setattr__(self, "_pos_cache", pc)
+        pos = pc[1].expand(N, T, 2)
         vec = self.local_mix(tok_emb, pos, focus_batch, ws_slots=None, use_dropout=self.cfg.ff_dropout)
         ent = getattr(self.local_mix.attn, "last_attn_entropy_b", None)
         return vec, self.local_mix.last_energy_b.detach(), (ent.detach() if ent is not None else None)
