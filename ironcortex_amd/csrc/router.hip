@@ -82,11 +82,16 @@ __global__ __launch_bounds__(256) void k_router_fwd_ms(ic_router_args a) {
 
 // ---------------------------------------------------------------- precision: edge GEMVs
 // y < E: message + key of edge e;  y >= E: query of region y-E.
-template <int DCH>
+// PP: row pairs per wave, i.e. 8 * PP rows of every matrix per workgroup.  1 where launches are the cost (the loop's
+// k_front); 2 or 4 on large maps, where the (slice, edge) grid is tens of thousands of workgroups of which a fifth find
+// an active sender and each asked for only 4 KB (110 k workgroups at R=512: the dispatch was the launch).  Every row's
+// dot products are the same wave reductions whatever PP: bit-identical results.
+template <int DCH, int PP = 1>
 __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const int y) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
-  const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
+  constexpr int NR = 2 * PP;  // rows per wave
+  const int row0 = blockIdx.x * (kRowsPerBlock * PP) + wave * NR;
   if (row0 >= d) return;
   const size_t dd = (size_t)d * d;
   // Streams z, z + nz, ... of this grid slice are tested 64 at a time (one mask byte per lane, one ballot) and
@@ -95,7 +100,7 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
   const int nz = gridDim.z;
   if (y < a.E) {
     const int e = y, src = a.src[e];
-    RowFrag<DCH> w0, w1, k0, k1;
+    RowFrag<DCH> w[NR], k[NR];
     float bias = 0.f;
     bool loaded = false;
     for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
@@ -105,10 +110,16 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
       if (!loaded) {  // (wave-uniform) idle workgroups never ask for their rows
         const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
         const float* K = a.key_W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
-        load_row(w0, W, d, lane);
-        load_row(w1, W + d, d, lane);
-        load_row(k0, K, d, lane);
-        load_row(k1, K + d, d, lane);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          if (row0 + i < d) {
+            load_row(w[i], W + (size_t)i * d, d, lane);
+            load_row(k[i], K + (size_t)i * d, d, lane);
+          } else {
+            zero_frag(w[i]);
+            zero_frag(k[i]);
+          }
+        }
         bias = a.ebias[e];
         loaded = true;
       }
@@ -127,12 +138,15 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (sv[u] < 0) continue;  // wave-uniform
-          const float m0 = wave_sum(dot_frag(w0, h[u])), m1 = wave_sum(dot_frag(w1, h[u]));
-          const float q0 = wave_sum(dot_frag(k0, h[u])), q1 = wave_sum(dot_frag(k1, h[u]));
-          if (lane < 2) {
-            const size_t idx = ((size_t)sv[u] * a.E + e) * d + row0 + lane;
-            a.msg[idx] = (lane ? m1 : m0) * bias;
-            a.keyv[idx] = lane ? q1 : q0;
+#pragma unroll
+          for (int p = 0; p < PP; ++p) {
+            const float m0 = wave_sum(dot_frag(w[2 * p], h[u])), m1 = wave_sum(dot_frag(w[2 * p + 1], h[u]));
+            const float q0 = wave_sum(dot_frag(k[2 * p], h[u])), q1 = wave_sum(dot_frag(k[2 * p + 1], h[u]));
+            if (lane < 2 && row0 + 2 * p + lane < d) {
+              const size_t idx = ((size_t)sv[u] * a.E + e) * d + row0 + 2 * p + lane;
+              a.msg[idx] = (lane ? m1 : m0) * bias;
+              a.keyv[idx] = lane ? q1 : q0;
+            }
           }
         }
       }
@@ -141,7 +155,7 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
     const int r = y - a.E;
     const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
     const float* Q = a.query_W + (size_t)r * dd + (size_t)row0 * d;
-    RowFrag<DCH> q0, q1;
+    RowFrag<DCH> q[NR];
     bool loaded = false;
     for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
       const int sl = sc + lane * nz;
@@ -151,8 +165,11 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
       unsigned long long act = __ballot(on);
       if (!act) continue;
       if (!loaded) {
-        load_row(q0, Q, d, lane);
-        load_row(q1, Q + d, d, lane);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          if (row0 + i < d) load_row(q[i], Q + (size_t)i * d, d, lane);
+          else zero_frag(q[i]);
+        }
         loaded = true;
       }
       while (act) {
@@ -170,17 +187,20 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (sv[u] < 0) continue;
-          const float v0 = wave_sum(dot_frag(q0, h[u])), v1 = wave_sum(dot_frag(q1, h[u]));
-          if (lane < 2) a.q[((size_t)sv[u] * a.R + r) * d + row0 + lane] = lane ? v1 : v0;
+#pragma unroll
+          for (int p = 0; p < PP; ++p) {
+            const float v0 = wave_sum(dot_frag(q[2 * p], h[u])), v1 = wave_sum(dot_frag(q[2 * p + 1], h[u]));
+            if (lane < 2 && row0 + 2 * p + lane < d) a.q[((size_t)sv[u] * a.R + r) * d + row0 + 2 * p + lane] = lane ? v1 : v0;
+          }
         }
       }
     }
   }
 }
 
-template <int DCH>
+template <int DCH, int PP>
 __global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
-  router_edge_body<DCH>(a, blockIdx.y);
+  router_edge_body<DCH, PP>(a, blockIdx.y);
 }
 
 // ---------------------------------------------------------------- gate + router in one launch
@@ -1098,8 +1118,21 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
     return IC_OK;
   }
   if (a->flags & IC_RF_PRECISION) {
+    // rows per workgroup: 8 while the (slice, edge) grid is small, 16 / 32 on large maps at d <= 256 (register budget;
+    // IC_EDGE_ROWS=8/16/32 forces one: A/B timing, same results bit for bit)
+    static const int rows_env = [] { const char* e = getenv("IC_EDGE_ROWS"); return e && e[0] ? atoi(e) : 0; }();
+    int pp = 1;
+    if (a->d <= 256) {
+      const int64_t wgs8 = (int64_t)nsl * (a->E + a->R);
+      pp = wgs8 >= 32768 ? 4 : (wgs8 >= 8192 ? 2 : 1);
+      if (rows_env == 8 || rows_env == 16 || rows_env == 32) pp = rows_env / 8;
+    }
+    const int nslp = ic_ceil_div(a->d, kRowsPerBlock * pp);
+    const dim3 ge(nslp, a->E + a->R, edge_nz(a->S, (int64_t)nslp * (a->E + a->R)));
     IC_DISPATCH_DCH(a->d, {
-      IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL(k_router_edge_fwd<DCH>, dim3(nsl, a->E + a->R, edge_nz(a->S, (int64_t)nsl * (a->E + a->R))), dim3(256), 0, st, *a));
+      if (pp == 4) IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 4>), ge, dim3(256), 0, st, *a));
+      else if (pp == 2) IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 2>), ge, dim3(256), 0, st, *a));
+      else IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 1>), ge, dim3(256), 0, st, *a));
     });
     const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
     if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
