@@ -24,29 +24,33 @@ constexpr int kRowsPerBlock = 8;
 // (each wave owns its two rows of every stream: no conflicts, no barrier until the write-out),
 // accumulated edge by edge in index order.  R=512, k=32, d=256: 26 us at S=1 (1.9 TB/s), 76 us at
 // S=8 (4.1 TB/s), 278 us at S=64 (2.7 TB/s).
-template <int DCH>
+template <int DCH, int PP = 1>
 __device__ __forceinline__ void router_fwd_ms_body(const ic_router_args& a, const int r) {
-  __shared__ float acc[64][kRowsPerBlock];
+  constexpr int RB = kRowsPerBlock * PP, NR = 2 * PP;  // rows per workgroup / per wave (PP > 1: large maps, see k_router_edge_fwd)
+  __shared__ float acc[64][RB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = a.d;
-  const int row0 = blockIdx.x * kRowsPerBlock + wave * 2;
-  const bool rows_ok = row0 < d;  // d % 4 == 0: a wave's two rows are valid together
+  const int row0 = blockIdx.x * RB + wave * NR;
+  const bool rows_ok = row0 < d;  // d % 4 == 0: a wave's row pairs are valid together
   const int e0 = a.dst_off[r], e1 = a.dst_off[r + 1];
   const size_t dd = (size_t)d * d;
   for (int sc = 0; sc < a.S; sc += 64) {
     const int n = a.S - sc < 64 ? a.S - sc : 64;
     if (lane < n) {
-      acc[lane][wave * 2] = 0.f;
-      acc[lane][wave * 2 + 1] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) acc[lane][wave * NR + i] = 0.f;
     }
     for (int e = e0; e < e1 && rows_ok; ++e) {
       const int src = a.src[e];
       unsigned long long act = __ballot(lane < n && prev_on(a, sc + lane, src));
       if (!act) continue;
       const float* W = a.W + (size_t)a.widx[e] * dd + (size_t)row0 * d;
-      RowFrag<DCH> w0, w1, h, hn;
-      load_row(w0, W, d, lane);
-      load_row(w1, W + d, d, lane);
+      RowFrag<DCH> w[NR], h, hn;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        if (row0 + i < d) load_row(w[i], W + (size_t)i * d, d, lane);
+        else zero_frag(w[i]);
+      }
       const float bias = a.ebias[e];
       int si = __ffsll((long long)act) - 1;
       act &= act - 1;
@@ -55,29 +59,32 @@ __device__ __forceinline__ void router_fwd_ms_body(const ic_router_args& a, cons
         const int sn = act ? __ffsll((long long)act) - 1 : -1;
         act &= act - 1;
         if (sn >= 0) load_row(hn, h_row(a, sc + sn, src), d, lane);  // next stream's sender row in flight
-        const float m0 = wave_sum(dot_frag(w0, h)), m1 = wave_sum(dot_frag(w1, h));
-        if (lane == 0) {
-          acc[si][wave * 2] += m0 * bias;  // gate.py:290,324 (w == 1)
-          acc[si][wave * 2 + 1] += m1 * bias;
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+          const float m0 = wave_sum(dot_frag(w[2 * p], h)), m1 = wave_sum(dot_frag(w[2 * p + 1], h));
+          if (lane == 0) {
+            acc[si][wave * NR + 2 * p] += m0 * bias;  // gate.py:290,324 (w == 1)
+            acc[si][wave * NR + 2 * p + 1] += m1 * bias;
+          }
         }
         h = hn;
         si = sn;
       }
     }
     __syncthreads();
-    // write-out: thread t -> (stream t / 8, row t % 8), 32 streams per pass
-    for (int base = 0; base < n; base += 32) {
-      const int s_l = base + (threadIdx.x >> 3), rr = threadIdx.x & 7;
-      const int row = blockIdx.x * kRowsPerBlock + rr;
+    // write-out: thread t -> (stream t / RB, row t % RB), 256 / RB streams per pass
+    for (int base = 0; base < n; base += 256 / RB) {
+      const int s_l = base + (int)threadIdx.x / RB, rr = (int)threadIdx.x % RB;
+      const int row = blockIdx.x * RB + rr;
       if (s_l < n && row < d) a.M[((size_t)(sc + s_l) * a.R + r) * d + row] = acc[s_l][rr];
     }
     __syncthreads();
   }
 }
 
-template <int DCH>
+template <int DCH, int PP>
 __global__ __launch_bounds__(256) void k_router_fwd_ms(ic_router_args a) {
-  router_fwd_ms_body<DCH>(a, blockIdx.y);
+  router_fwd_ms_body<DCH, PP>(a, blockIdx.y);
 }
 
 // ---------------------------------------------------------------- precision: edge GEMVs
@@ -1143,7 +1150,20 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
     int rc2 = ic_router_shared_fwd_launch(a, st);
     if (rc2) return rc2;
   } else {
-    IC_DISPATCH_DCH(a->d, { IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL(k_router_fwd_ms<DCH>, dim3(nsl, a->R), dim3(256), 0, st, *a)); });
+    // rows per workgroup as for the precision edge kernel (IC_ROUTER_ROWS=8/16/32 forces one; same results)
+    static const int rrows_env = [] { const char* e = getenv("IC_ROUTER_ROWS"); return e && e[0] ? atoi(e) : 0; }();
+    int pp = 1;
+    if (a->d <= 256) {
+      const int64_t wgs8 = (int64_t)nsl * a->R;
+      pp = wgs8 >= 16384 ? 4 : (wgs8 >= 4096 ? 2 : 1);
+      if (rrows_env == 8 || rrows_env == 16 || rrows_env == 32) pp = rrows_env / 8;
+    }
+    const dim3 gr(ic_ceil_div(a->d, kRowsPerBlock * pp), a->R);
+    IC_DISPATCH_DCH(a->d, {
+      if (pp == 4) IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd_ms<DCH, 4>), gr, dim3(256), 0, st, *a));
+      else if (pp == 2) IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd_ms<DCH, 2>), gr, dim3(256), 0, st, *a));
+      else IC_TIMED(IC_KID_router_fwd, st, hipLaunchKernelGGL((k_router_fwd_ms<DCH, 1>), gr, dim3(256), 0, st, *a));
+    });
   }
   IC_LAUNCH_CHECK("ic_router_fwd");
   return IC_OK;
