@@ -232,6 +232,13 @@ typedef struct ic_router_args {
   float* fact_t;            /* [S,R,d] saved: V h of the active senders, zeros elsewhere */
   float* fact_z;            /* [S,R,d] saved: sum over the active in-edges of ebias_e * w_e * t[src_e] */
   uint8_t* fact_dact;       /* [S,R]   saved: 1 if the region has an active in-edge */
+  /* IC_RF_SHARED, optional: workspace of 512 + 2*S*R 32-bit words.  With it (and S*R >= 4096) the forward GEMM walks the
+   * (stream, destination) columns in an order SORTED by which directions have an active in-edge, so that a 32-column
+   * tile skips the matrices none of its columns uses, and the data-gradient GEMM of ic_router_bwd (through .f) walks
+   * the active senders first: the matrix cores only multiply active rows (the results are the same bit for bit:
+   * every column's sums are its own).  Calls sharing one workspace must be ordered on one stream.
+   * NULL: columns in (stream, region) order. */
+  int32_t* shared_ws;
 } ic_router_args;
 int ic_router_fwd(const ic_router_args* a, ic_stream_t stream);
 

@@ -31,7 +31,66 @@ __device__ __forceinline__ void mfma_chunk(const float (*As)[kTK + 1], const flo
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[ai][kk + kh], Bs[kk + kh][bj], acc, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a) {
+// ---- columns sorted by activity pattern (ic_router_args.shared_ws: [0,256) counts, [256,512) cursors, [512,512+N) the
+// patterns, [512+N,512+2N) the permutation).  Forward (mode 0): pattern of column (s, r) = bit k set iff r has an
+// in-edge of direction k whose sender was active in stream s.  Backward (mode 1): 1 iff (s, r) itself was an active
+// sender.  k_shared_pattern counts the columns per pattern (LDS histogram, one global integer atomic per non-empty bin
+// and workgroup); k_shared_scatter gives every column a place inside its pattern's range: a rank among its workgroup's
+// columns of that pattern (LDS atomic) on top of a range the workgroup reserves with one global atomic per non-empty
+// bin.  The order INSIDE a pattern is whatever the atomics make it: it does not matter, every column's result is its
+// own and is written to the column's own place.
+constexpr int kPatBins = 256, kPermHdr = 512, kSortMinCols = 64;  // (below two tiles there is nothing to sort; the caller decides from where it pays)
+__global__ __launch_bounds__(256) void k_shared_pattern(ic_router_args a, int mode) {
+  __shared__ int hist[kPatBins];
+  const int N = a.S * a.R, n = blockIdx.x * 256 + threadIdx.x;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  if (n < N) {
+    const int s = n / a.R, r = n % a.R;
+    int pat = 0;
+    if (mode == 0) {
+      for (int e = a.dst_off[r]; e < a.dst_off[r + 1]; ++e)
+        if (prev_on(a, s, a.src[e])) pat |= 1 << a.widx[e];
+      pat &= kPatBins - 1;
+    } else {
+      pat = prev_on(a, s, r) ? 1 : 0;
+    }
+    pat = ~pat & (kPatBins - 1);  // sort key: the complement, so that all-inactive columns come LAST (their tiles only write zeros)
+    a.shared_ws[kPermHdr + n] = pat;
+    atomicAdd(&hist[pat], 1);
+  }
+  __syncthreads();
+  if (hist[threadIdx.x]) atomicAdd(&a.shared_ws[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_shared_scatter(ic_router_args a) {
+  __shared__ int scan[2][kPatBins], mine[kPatBins], start[kPatBins];
+  const int N = a.S * a.R, t = threadIdx.x, n = blockIdx.x * 256 + t;
+  const int cnt = a.shared_ws[t];
+  scan[0][t] = cnt;
+  mine[t] = 0;
+  __syncthreads();
+  int cur = 0;
+  for (int off = 1; off < kPatBins; off <<= 1, cur ^= 1) {  // inclusive prefix over the 256 pattern counts
+    scan[cur ^ 1][t] = scan[cur][t] + (t >= off ? scan[cur][t - off] : 0);
+    __syncthreads();
+  }
+  const int base_t = scan[cur][t] - cnt;  // exclusive prefix: where key t's range starts
+  int pat = 0, rank = 0;
+  if (n < N) {
+    pat = a.shared_ws[kPermHdr + n];
+    rank = atomicAdd(&mine[pat], 1);
+  }
+  __syncthreads();
+  if (mine[t]) start[t] = base_t + atomicAdd(&a.shared_ws[kPatBins + t], mine[t]);
+  __syncthreads();
+  if (n < N) {
+    const int pos = start[pat] + rank;
+    if (pos >= 0 && pos < N) a.shared_ws[kPermHdr + N + pos] = n;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a, const int32_t* perm) {
   __shared__ float As[kTM][kTK + 1];
   __shared__ float Bs[kTK][kTN + 1];
   __shared__ int tsrc[kMaxShared][kTN];
@@ -42,11 +101,18 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
   const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * kTN;
   if (tid < kMaxShared) any_k[tid] = 0;
   __syncthreads();
+  __shared__ int tcol[kTN];
+  if (tid < kTN) {  // this tile's columns: in (stream, region) order, or through the sorted permutation
+    int n = col0 + tid;
+    if (perm && n < N) n = perm[n];
+    tcol[tid] = (unsigned)n < (unsigned)N ? n : -1;
+  }
+  __syncthreads();
   {  // per column and shared matrix: the sender row and bias of the (unique) active in-edge, or -1
-    const int c = tid & 31, k = tid >> 5, n = col0 + c;
+    const int c = tid & 31, k = tid >> 5, n = tcol[c];
     int srow = -1;
     float sc = 0.f;
-    if (k < a.nW && n < N) {
+    if (k < a.nW && n >= 0) {
       const int s = n / a.R, r = n % a.R;
       for (int e = a.dst_off[r]; e < a.dst_off[r + 1]; ++e) {
         if (a.widx[e] == k && prev_on(a, s, a.src[e])) {
@@ -73,7 +139,7 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
     const int ar = tid >> 1, ah = (tid & 1) * 16, agrow = row0 + ar;
     const int bc = tid >> 3, bks = (tid & 7) * 4, bsrow = tsrc[k][bc];
     const float bsc = tscale[k][bc];
-    const float* brow = bsrow >= 0 ? h_row(a, (col0 + bc) / a.R, bsrow) : nullptr;
+    const float* brow = bsrow >= 0 ? h_row(a, tcol[bc] / a.R, bsrow) : nullptr;
     float4 av[4], bv;
     auto fetch = [&](int kk0) {
 #pragma unroll
@@ -96,8 +162,8 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
       __syncthreads();
     }
   }
-  const int j = lane & 31, n = col0 + j;
-  if (n < N) {
+  const int j = lane & 31, n = tcol[j];
+  if (n >= 0) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int i = row0 + wave * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
@@ -347,7 +413,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(ic_wgrad_edge_args a, int 
 //   before the edge bias is applied, so d/d ebias_e = (W_k^T g) . h_sender comes out of the same accumulators
 //   (this workgroup's 128 rows: partial blockIdx.x of g_ebias_part).  Output-stationary like the forward: every
 //   (stream, sender) row of gH is written once, zeros for inactive senders; no slabs, no gather launch.
-__global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_args b) {
+__global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_args b, const int32_t* perm) {
   const ic_router_args& a = b.f;
   __shared__ float As[kTM][kTK + 1];
   __shared__ float Bs[kTK][kTN + 1];
@@ -358,13 +424,19 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = a.d, N = a.S * a.R;
   const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * kTN;
+  __shared__ int tcol[kTN];
   if (tid < kMaxShared) any_k[tid] = 0;
+  if (tid < kTN) {  // this tile's columns: in (stream, region) order, or active senders first (sorted permutation)
+    int n = col0 + tid;
+    if (perm && n < N) n = perm[n];
+    tcol[tid] = (unsigned)n < (unsigned)N ? n : -1;
+  }
   __syncthreads();
   {  // per column and matrix: the out-edge of the column's sender, its destination and bias, or -1
-    const int c = tid & 31, k = tid >> 5, n = col0 + c;
+    const int c = tid & 31, k = tid >> 5, n = tcol[c];
     int dst = -1, edge = -1;
     float sc = 0.f;
-    if (k < a.nW && n < N) {
+    if (k < a.nW && n >= 0) {
       const int s = n / a.R, r = n % a.R;
       if (prev_on(a, s, r)) {  // (no in_slot / sk on this path: ic_router_bwd checks)
         for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
@@ -389,13 +461,13 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
     if (dst >= 0) any_k[k] = 1;
   }
   __syncthreads();
-  const int j = lane & 31, n = col0 + j;
-  const int s_col = n < N ? n / a.R : 0, r_col = n < N ? n % a.R : 0;
+  const int j = lane & 31, n = tcol[j];
+  const int s_col = n >= 0 ? n / a.R : 0, r_col = n >= 0 ? n % a.R : 0;
   // this lane's 16 rows of its column's sender state (for d/d ebias)
   float hv[16];
 #pragma unroll
   for (int v = 0; v < 16; ++v) hv[v] = 0.f;
-  if (n < N) {
+  if (n >= 0) {
     const float* hrow = h_row(a, s_col, r_col);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -420,7 +492,7 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
     // B[kk][c] = gM[s, dst][kk0 + kk]; thread -> (column tid / 8, 4 k's); next chunk prefetched into registers
     const int akk = tid >> 3, ai0 = (tid & 7) * 16;
     const int bc = tid >> 3, bks = (tid & 7) * 4, bdst = tdst[k][bc];
-    const float* brow = bdst >= 0 ? b.gM + ((size_t)((col0 + bc) / a.R) * a.R + bdst) * d : nullptr;
+    const float* brow = bdst >= 0 ? b.gM + ((size_t)(tcol[bc] / a.R) * a.R + bdst) * d : nullptr;
     float4 av[4], bv;
     auto fetch = [&](int kk0) {
 #pragma unroll
@@ -453,13 +525,13 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
     for (int v = 0; v < 16; ++v) tot[v] = fmaf(sc, acc[v], tot[v]);
     __syncthreads();
     if (tid < kTN) {
-      const int e = tedge[k][tid], nn = col0 + tid;
-      if (e >= 0 && nn < N)
+      const int e = tedge[k][tid], nn = tcol[tid];
+      if (e >= 0 && nn >= 0)
         b.g_ebias_part[(size_t)blockIdx.x * SE + (size_t)(nn / a.R) * a.E + e] = (pb[0][tid] + pb[1][tid]) + (pb[2][tid] + pb[3][tid]);
     }
     __syncthreads();
   }
-  if (n < N) {
+  if (n >= 0) {
     float* out = b.gH + (size_t)n * d;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -471,11 +543,28 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
 
 }  // namespace
 
+// The sorted permutation of the columns (mode 0: forward patterns, 1: active senders first) in a->shared_ws, when the
+// caller brought one and the map is large enough for the two small launches to pay; *perm stays null otherwise.
+static int shared_sort(const ic_router_args* a, int mode, hipStream_t st, const int32_t** perm) {
+  const int N = a->S * a->R;
+  if (!a->shared_ws || N < kSortMinCols || a->nW > 8) return IC_OK;
+  if (hipMemsetAsync(a->shared_ws, 0, kPermHdr * sizeof(int32_t), st) != hipSuccess) {
+    ic_set_error("ic_router: hipMemsetAsync of the column-sort counters failed");
+    return IC_ELAUNCH;
+  }
+  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_shared_pattern, dim3(ic_ceil_div(N, 256)), dim3(256), 0, st, *a, mode));
+  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_shared_scatter, dim3(ic_ceil_div(N, 256)), dim3(256), 0, st, *a));
+  *perm = a->shared_ws + kPermHdr + N;
+  return IC_OK;
+}
+
 // library-internal launchers (router.hip: ic_router_fwd / ic_router_wgrad)
 int ic_router_shared_fwd_launch(const ic_router_args* a, hipStream_t st) {
   const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->S * a->R, kTN));
   IC_BYTES(IC_KID_router_mfma, 4.0 * ((double)a->nW * a->d * a->d + 2.0 * a->S * a->R * a->d));
-  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_fwd_mfma, grid, dim3(256), 0, st, *a));
+  const int32_t* perm = nullptr;
+  if (const int rc = shared_sort(a, 0, st, &perm)) return rc;
+  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_fwd_mfma, grid, dim3(256), 0, st, *a, perm));
   return IC_OK;
 }
 
@@ -504,6 +593,8 @@ int ic_router_shared_dgrad_launch(const ic_router_bwd_args* b, int nslab, hipStr
   (void)nslab;
   const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->S * a->R, kTN));
   IC_BYTES(IC_KID_router_mfma, 4.0 * ((double)a->nW * a->d * a->d + 3.0 * a->S * a->R * a->d));
-  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_dgrad_mfma, grid, dim3(256), 0, st, *b));
+  const int32_t* perm = nullptr;
+  if (const int rc = shared_sort(a, 1, st, &perm)) return rc;
+  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_dgrad_mfma, grid, dim3(256), 0, st, *b, perm));
   return IC_OK;
 }

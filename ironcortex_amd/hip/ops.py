@@ -240,6 +240,12 @@ class Tape:
         self.pos = 0
 
 
+# IC_SHARED_SORT=0: the shared-matrix (by_direction) forward GEMM walks its columns in (stream, region) order instead of
+# sorted by activity pattern (A/B timing; same results bit for bit)
+SHARED_SORT = os.environ.get("IC_SHARED_SORT", "1") != "0"
+SHARED_SORT_MIN = int(os.environ.get("IC_SHARED_SORT_MIN", "4096"))  # columns (streams x regions) from which the sort is used
+_SHARED_WS: Dict[tuple, torch.Tensor] = {}
+
 # IC_WGRAD_GEMM=0: the deferred per-edge / per-region weight gradients always through the row-slice kernels (A/B timing)
 WGRAD_GEMM = os.environ.get("IC_WGRAD_GEMM", "1") != "0"
 WGRAD_GEMM_MIN_TS = 64  # (stream, slot) pairs on the tapes from which the pair-list GEMM is used
@@ -473,6 +479,15 @@ def _router_args(spec: RouterSpec, T: Dict[str, torch.Tensor], P: Dict[str, torc
     a.W = P["W"].data_ptr()
     if spec.precision:
         a.key_W, a.query_W, a.raw_P = P["key_W"].data_ptr(), P["query_W"].data_ptr(), P["raw_P"].data_ptr()
+    elif spec.shared_gemm and SHARED_SORT and S * spec.R >= SHARED_SORT_MIN:
+        # workspace of the column sort (ic_router_args.shared_ws): one per (columns, device, stream) -- calls that share
+        # one are ordered on that stream -- reused by every call (forward and data gradient)
+        dev = T["dst_off"].device
+        key = (S * spec.R, dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _SHARED_WS.get(key)
+        if ws is None:
+            ws = _SHARED_WS[key] = torch.zeros(512 + 2 * S * spec.R, dtype=torch.int32, device=dev)
+        a.shared_ws = ws.data_ptr()
     return a
 
 

@@ -60,15 +60,20 @@ def main():
         flops_fwd = 2.0 * d * (router.nW * d) * n_cols              # [d, 6d] x [6d, S*R], zero columns included
         pairs = float(mask.bool()[:, router.src_idx].sum())
         flops_wgrad = 2.0 * d * d * pairs                            # sum over directions of [d, P_k] x [P_k, d]
-        row = {"R": R, "S": S, "d": d, "active_fraction": args.p, "columns": n_cols, "active_edge_pairs": pairs,
+        row = {"sorted_columns": bool(hip.ops.SHARED_SORT and n_cols >= hip.ops.SHARED_SORT_MIN), "R": R, "S": S, "d": d, "active_fraction": args.p, "columns": n_cols, "active_edge_pairs": pairs,
                "fwd_GFLOP": flops_fwd / 1e9, "wgrad_GFLOP": flops_wgrad / 1e9, "peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS, "kernels": {}}
         for name, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
             us = ms / args.iters * 1e3  # per call of the op (the weight gradient is up to three launches: list, GEMM, reduce)
             k = {"us_per_call": round(us, 2), "launches_per_call": n / args.iters}
+            # router_mfma = the forward GEMM + the data-gradient GEMM (+ their column sorts, ops.SHARED_SORT): "TFLOPs" prices
+            # ONE dense forward (zero columns included, the figure of earlier rounds), "useful_TFLOPs" the multiplications of
+            # active (edge, stream) pairs only, forward and data gradient together
             fl = {"router_mfma": flops_fwd, "wgrad_mfma": flops_wgrad}.get(name)
             if fl:
                 k["TFLOPs"] = round(fl / (us * 1e-6) / 1e12, 2)
                 k["frac_of_fp32_mfma_peak"] = round(k["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, 4)
+            if name == "router_mfma":
+                k["useful_TFLOPs"] = round(2 * flops_wgrad / (us * 1e-6) / 1e12, 2)
             row["kernels"][name] = k
         print(json.dumps(row), flush=True)
 

@@ -323,6 +323,57 @@ def test_router_by_direction_mfma_vs_oracle(R, S, d):
     PL.flush(_TAG[0])
 
 
+@pytest.mark.parametrize("R,S,d,p_on", [(128, 32, 64, 0.3), (100, 41, 48, 0.06), (256, 16, 256, 0.0625)])
+def test_router_by_direction_sorted_columns(R, S, d, p_on, monkeypatch):
+    """From 4096 columns on, the shared-matrix forward GEMM walks its columns sorted by activity pattern
+    (k_shared_pattern / k_shared_scatter, ic_router_args.shared_ws), so that a 32-column tile multiplies only the
+    direction matrices its columns use, and the data-gradient GEMM walks the active senders first.  Every column's
+    result is its own: outputs and gradients must equal the unsorted kernels' bit for bit (twice in a row: the workspace header is cleared per call), and the oracle's on sampled
+    streams (gate.py:142-149,274-277)."""
+    from ironcortex_amd.gate import Router
+    from ironcortex_amd.hip import ops
+    from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
+    from oracle import hotpath as O
+    seed = 8100 + R + S
+    nb = hex_neighbors(R)
+    coords = hex_axial_coords(R)
+    router = Router(nb, d, R, edge_transform_mode="by_direction").to(DEV)
+    W_dir = gi.det(seed + 1, 6, d, d, kind="xavier")
+    t = dict(W_reg=gi.det(seed + 5, 8, 2), beta_cos=gi.det(seed + 6, 8, scale=0.3), beta_sin=gi.det(seed + 7, 8, scale=0.3))
+    with torch.no_grad():
+        router._flat.stacked("W").copy_(W_dir)
+        router.W_reg.copy_(t["W_reg"]); router.beta_cos.copy_(t["beta_cos"]); router.beta_sin.copy_(t["beta_sin"])
+    mask = gi.det(seed + 2, S, R, kind="rand") < p_on
+    mask[S - 1] = False
+    H = gi.det(seed + 8, S, R, d) * mask.unsqueeze(-1)
+    gM = gi.det(seed + 9, S, R, d).to(DEV)
+    outs = {}
+    for sort in (True, False, True):
+        monkeypatch.setattr(ops, "SHARED_SORT", sort)
+        for p in router.parameters():
+            p.grad = None
+        Hg = H.to(DEV).requires_grad_(True)
+        M = router.route(Hg, mask.to(torch.uint8).to(DEV), coords.to(DEV))
+        assert router._shared_gemm
+        (M * gM).sum().backward()
+        got = (M.detach().clone(), Hg.grad.clone(), router.beta_cos.grad.clone(), router.beta_sin.grad.clone(),
+               torch.stack([l.weight.grad.clone() for l in router.W_dir]))
+        if sort in outs:
+            for x, y in zip(got, outs[sort]):
+                assert torch.equal(x, y), "second sorted call differs from the first"
+        outs[sort] = got
+    assert any(k[0] == S * R for k in ops._SHARED_WS)
+    assert float(outs[True][0].abs().sum()) > 0 and float(outs[True][1].abs().sum()) > 0
+    for x, y, what in zip(outs[True], outs[False], ("M", "g.H", "g.beta_cos", "g.beta_sin", "g.W_dir")):
+        assert torch.equal(x, y), f"{what}: sorted and unsorted columns differ"
+    outs = {k: v[0] for k, v in outs.items()}
+    P = {"W_dir": [W_dir[k] for k in range(6)], "W_reg": t["W_reg"], "beta_cos": t["beta_cos"], "beta_sin": t["beta_sin"]}
+    _TAG[0] = f"by_direction-sorted/R{R}/S{S}/d{d}"
+    for s in (0, S // 2, S - 1):
+        close(outs[True][s], O.router_messages(P, H[s], mask[s], coords, nb, mode="by_direction")[0], what=f"M[{s}]")
+    PL.flush(_TAG[0])
+
+
 @pytest.mark.parametrize("R,S,d", [(36, 4, 256), (64, 8, 256), (10, 3, 48)])
 def test_router_factorized_lib_vs_oracle(R, S, d, monkeypatch):
     """edge_transform_mode="factorized" (gate.py:150-159,278-281) on the library (IC_RF_FACTORIZED): V h per active
