@@ -1063,6 +1063,7 @@ static ic_router_args fact_rows(const ic_router_args* a, const float* W) {
   p.S = a->S; p.R = a->R; p.d = a->d; p.E = a->R; p.flags = IC_RF_SHARED; p.nW = 1;
   p.dst_off = a->fact_iota; p.src = a->fact_iota; p.widx = a->fact_zero;
   p.W = W; p.ebias = a->fact_ones;
+  p.shared_ws = a->shared_ws;  // (the column sort of the row GEMMs: active rows only)
   return p;
 }
 

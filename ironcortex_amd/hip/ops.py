@@ -475,11 +475,11 @@ def _router_args(spec: RouterSpec, T: Dict[str, torch.Tensor], P: Dict[str, torc
     if spec.factorized:  # msg_e = ebias_e U (w_e * V h): two shared matrices + per-edge scales, identity tables of the row GEMMs
         a.fact_U, a.fact_V, a.fact_w = P["U"].data_ptr(), P["V"].data_ptr(), P["w_e"].data_ptr()
         a.fact_iota, a.fact_zero, a.fact_ones = T["iota"].data_ptr(), T["zero"].data_ptr(), T["ones"].data_ptr()
-        return a
-    a.W = P["W"].data_ptr()
+    else:
+        a.W = P["W"].data_ptr()
     if spec.precision:
         a.key_W, a.query_W, a.raw_P = P["key_W"].data_ptr(), P["query_W"].data_ptr(), P["raw_P"].data_ptr()
-    elif spec.shared_gemm and SHARED_SORT and S * spec.R >= SHARED_SORT_MIN:
+    elif (spec.shared_gemm or spec.factorized) and SHARED_SORT and S * spec.R >= SHARED_SORT_MIN:
         # workspace of the column sort (ic_router_args.shared_ws): one per (columns, device, stream) -- calls that share
         # one are ordered on that stream -- reused by every call (forward and data gradient)
         dev = T["dst_off"].device

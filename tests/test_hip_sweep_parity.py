@@ -434,3 +434,40 @@ def test_router_factorized_lib_vs_oracle(R, S, d, monkeypatch):
     for e, k in enumerate(router.edge_keys):
         assert (router.w_edge[k].grad is not None) == bool(act[e]), k
     PL.flush(_TAG[0])
+
+
+@pytest.mark.parametrize("R,S,d,p_on", [(128, 32, 64, 0.3), (256, 16, 256, 0.0625)])
+def test_router_factorized_sorted_columns(R, S, d, p_on, monkeypatch):
+    """The two row GEMMs of the factorized mode (t = V h over the active senders, M = U z over the destinations with
+    an active in-edge; gate.py:150-159,278-281) and their input gradients take the column sort too
+    (fact_rows passes ic_router_args.shared_ws on): outputs and gradients equal the unsorted run's bit for bit."""
+    from ironcortex_amd.gate import Router
+    from ironcortex_amd.hip import ops
+    from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
+    seed = 8300 + R + S
+    router = Router(hex_neighbors(R), d, R, edge_transform_mode="factorized").to(DEV)
+    assert router.fact_lib
+    monkeypatch.setattr(router, "_route_factorized", None)
+    coords = hex_axial_coords(R).to(DEV)
+    with torch.no_grad():
+        router.U.weight.copy_(gi.det(seed + 1, d, d, kind="xavier")); router.V.weight.copy_(gi.det(seed + 2, d, d, kind="xavier"))
+        router.beta_cos.copy_(gi.det(seed + 6, 8, scale=0.3)); router.beta_sin.copy_(gi.det(seed + 7, 8, scale=0.3))
+    mask = gi.det(seed + 4, S, R, kind="rand") < p_on
+    mask[S - 1] = False
+    H = gi.det(seed + 8, S, R, d) * mask.unsqueeze(-1)
+    gM = gi.det(seed + 9, S, R, d).to(DEV)
+    outs = {}
+    for sort in (True, False):
+        monkeypatch.setattr(ops, "SHARED_SORT", sort)
+        for p in router.parameters():
+            p.grad = None
+        Hg = H.to(DEV).requires_grad_(True)
+        M = router.route(Hg, mask.to(torch.uint8).to(DEV), coords)
+        (M * gM).sum().backward()
+        gw = torch.stack([router.w_edge[k].grad.clone() if router.w_edge[k].grad is not None else torch.zeros(d, device=DEV)
+                          for k in router.edge_keys])
+        outs[sort] = (M.detach().clone(), Hg.grad.clone(), router.U.weight.grad.clone(), router.V.weight.grad.clone(), gw,
+                      router.beta_cos.grad.clone(), router.beta_sin.grad.clone())
+    assert float(outs[True][0].abs().sum()) > 0 and float(outs[True][1].abs().sum()) > 0
+    for x, y, what in zip(outs[True], outs[False], ("M", "g.H", "g.U", "g.V", "g.w_edge", "g.beta_cos", "g.beta_sin")):
+        assert torch.equal(x, y), f"{what}: sorted and unsorted columns differ"
