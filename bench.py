@@ -53,13 +53,19 @@ def make_config(name: str):
                             enable_radial_tangential_updates=True, enable_afa_attention=True,
                             enable_ff_energy_alignment=True, enable_energy_verifier=True,
                             enable_forward_forward=True, debug_metrics_every_n_steps=2)
+    if name in ("bydir36", "fact36"):  # the default script config in a shared-matrix edge mode (A/B workloads, not `value`;
+        # forward-forward off: the reference's train_step raises AttributeError with it in these modes)
+        return CortexConfig(R=36, d=256, V=256, K_inner=8, B_br=2, k_active=8, max_T=512, enable_forward_forward=False,
+                            edge_transform_mode="by_direction" if name == "bydir36" else "factorized")
     raise SystemExit(f"unknown --config {name}")
 
 
 WORKLOAD = {"10m": "train_tiny_shakespeare_10m.py config (R=10,d=256,all flags on)",
             "default": "train_tiny_shakespeare.py default config (R=36,d=256)",
             "r512": "configs[2] model level: 10M-script flags on R=512, k_active=32, d=256",
-            "r64": "configs[2] model level: 10M-script flags on R=64, k_active=32, d=256"}
+            "r64": "configs[2] model level: 10M-script flags on R=64, k_active=32, d=256",
+            "bydir36": "default script config (R=36,d=256), edge_transform_mode=by_direction, forward-forward off",
+            "fact36": "default script config (R=36,d=256), edge_transform_mode=factorized, forward-forward off"}
 
 
 def algorithmic_bytes(kernel: str, d: int, st: dict) -> float:

@@ -58,7 +58,11 @@ enum {
   IC_RF_SHARED = 1 << 1,    /* widx selects one of nW <= 8 matrices SHARED by many edges (edge_transform_mode
                                "by_direction", gate.py:142-149,274-277) and no destination has two incoming edges
                                with the same widx: without IC_RF_PRECISION the forward then runs as ONE GEMM
-                               [d, nW*d] x [nW*d, S*R] on the matrix cores (fp32 MFMA) instead of per-edge GEMVs */
+                               [d, nW*d] x [nW*d, S*R] on the matrix cores (fp32 MFMA) instead of per-edge GEMVs --
+                               from 8192 (stream, region) columns on: below, a tile's nW back-to-back K loops are a
+                               latency chain (~50 us at d=256) that the per-edge kernels, reading W[widx[e]] in place
+                               for the handful of active senders, undercut (9-45 us) */
+  IC_RF_SHARED_GEMM = 1 << 3, /* with IC_RF_SHARED: the GEMM whatever the number of columns */
   IC_RF_FACTORIZED = 1 << 2 /* edge_transform_mode "factorized" (gate.py:150-159,278-281): msg_e = ebias_e * U (w_e * V h_src)
                                with two matrices shared by ALL edges.  Without precision routing the messages of a
                                destination are summed, so M[dst] = U (sum_e ebias_e * w_e * (V h_src_e)): V once per
@@ -232,7 +236,7 @@ typedef struct ic_router_args {
   float* fact_t;            /* [S,R,d] saved: V h of the active senders, zeros elsewhere */
   float* fact_z;            /* [S,R,d] saved: sum over the active in-edges of ebias_e * w_e * t[src_e] */
   uint8_t* fact_dact;       /* [S,R]   saved: 1 if the region has an active in-edge */
-  /* IC_RF_SHARED, optional: workspace of 512 + 2*S*R 32-bit words.  With it (and S*R >= 4096) the forward GEMM walks the
+  /* IC_RF_SHARED, optional: workspace of 512 + 2*S*R 32-bit words.  With it (worth it from ~8192 columns on) the forward GEMM walks the
    * (stream, destination) columns in an order SORTED by which directions have an active in-edge, so that a 32-column
    * tile skips the matrices none of its columns uses, and the data-gradient GEMM of ic_router_bwd (through .f) walks
    * the active senders first: the matrix cores only multiply active rows (the results are the same bit for bit:

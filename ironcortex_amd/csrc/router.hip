@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int kRowsPerBlock = 8;
+constexpr int kSharedGemmMinCols = 8192;  // see shared_as_gemm
 
 // ---------------------------------------------------------------- default forward
 // Workgroup = (8-row slice, destination r); incoming edges are walked in index order (the
@@ -1057,6 +1058,17 @@ static int edge_nz(int S, int64_t base_wgs) {
   return nz;
 }
 
+// Shared matrices (by_direction) as ONE GEMM on the matrix cores, or through the per-edge kernels (which read W[widx[e]]
+// in place)?  A GEMM tile runs its (up to) nW K loops back to back whatever the number of columns: a latency chain of
+// ~50 us at d=256, against 9-45 us for the per-edge products of the few active senders of up to ~4096 (stream, region)
+// columns (scripts/bydir_small_bench.py).  From kSharedGemmMinCols columns on the GEMM wins; IC_RF_SHARED_GEMM in the
+// flags asks for it at any size, IC_SHARED_GEMM_MIN=<columns> in the environment moves the point.
+static bool shared_as_gemm(const ic_router_args* a) {
+  static const long long min_cols = [] { const char* e = getenv("IC_SHARED_GEMM_MIN"); return e && e[0] ? atoll(e) : (long long)kSharedGemmMinCols; }();
+  return (a->flags & IC_RF_SHARED) && !(a->flags & IC_RF_PRECISION) && a->E > 0 &&
+         ((a->flags & IC_RF_SHARED_GEMM) || (long long)a->S * a->R >= min_cols);
+}
+
 // the identity-table router of one of the two row GEMMs of the factorized mode: R self-edges, one shared matrix
 static ic_router_args fact_rows(const ic_router_args* a, const float* W) {
   ic_router_args p = {};
@@ -1146,7 +1158,7 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
     if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));
     else if (a->d <= 512) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<2>, gcomb, dim3(256), 0, st, *a));
     else IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine_serial<4>, gcomb, dim3(256), 0, st, *a));
-  } else if ((a->flags & IC_RF_SHARED) && a->E > 0) {  // by_direction: one GEMM on the matrix cores
+  } else if (shared_as_gemm(a)) {  // by_direction: one GEMM on the matrix cores
     IC_REQUIRE(a->nW >= 1 && a->nW <= 8, "ic_router_fwd: IC_RF_SHARED needs 1 <= nW <= 8 (nW=%d)", a->nW);
     int rc2 = ic_router_shared_fwd_launch(a, st);
     if (rc2) return rc2;
@@ -1174,7 +1186,7 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
 // routed region kernel that follows on the same stream.
 int ic_front_launch(const ic_gate_args* g, const ic_router_args* a, ic_stream_t stream, bool combine) {
   IC_REQUIRE(g != nullptr && a != nullptr, "ic_front_fwd: NULL args");
-  if (g->R > 64 || a->E == 0 || ((a->flags & IC_RF_SHARED) && !(a->flags & IC_RF_PRECISION)) || (a->flags & IC_RF_FACTORIZED)) {
+  if (g->R > 64 || a->E == 0 || shared_as_gemm(a) || (a->flags & IC_RF_FACTORIZED)) {
     // big maps: the gate's scores want the whole chip (ic_gate_fwd); shared matrices: the router is an MFMA GEMM
     IC_REQUIRE(combine, "ic_front_fwd: no fused launch for R=%d, E=%d", g->R, a->E);
     int rc = ic_gate_fwd(g, stream);
@@ -1238,10 +1250,12 @@ extern "C" int ic_router_bwd(const ic_router_bwd_args* b, ic_stream_t stream) {
   // the idle workgroups: 56 vs 29 us at R=512; 10M bench, S=16: 17 vs 33 us).  IC_BWD_SPLIT=0/1 forces one.
   static const int many_env = [] { const char* e = getenv("IC_BWD_SPLIT"); return (e && e[0]) ? (e[0] == '0' ? 0 : 1) : -1; }();
   const bool many = many_env >= 0 ? many_env == 1 : a->S >= 8;
-  // shared matrices without precision routing, streams laid out plainly: the input gradient is ONE MFMA GEMM
-  // (router_mfma.hip) in place of the per-edge transposed GEMVs and the gather
-  const bool dgrad_mfma = (a->flags & IC_RF_SHARED) && !(a->flags & IC_RF_PRECISION) && a->E > 0 && !b->in_slot && b->sk <= 1 &&
-                          b->gH_sstride == 0 && a->d % 4 == 0 && a->nW >= 1 && a->nW <= 8 && ic_ceil_div(a->d, 128) <= nslab;
+  // shared matrices without precision routing: the input gradient is ONE MFMA GEMM (router_mfma.hip) in place of the
+  // per-edge transposed GEMVs and the gather, whatever the stream addressing (in_slot / sk / gH_sstride)
+  static const int dgrad_env = [] { const char* e = getenv("IC_DGRAD_MFMA"); return (e && e[0]) ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool plain = !b->in_slot && b->sk <= 1 && b->gH_sstride == 0;
+  const bool dgrad_mfma = (a->flags & IC_RF_SHARED) && !(a->flags & IC_RF_PRECISION) && a->E > 0 && (plain || dgrad_env != 0) &&
+                          a->d % 4 == 0 && a->nW >= 1 && a->nW <= 8 && ic_ceil_div(a->d, 128) <= nslab;
   if (a->d <= 256) {
     constexpr int DCH = 1;
     IC_TIMED(IC_KID_router_comb_bwd, st, hipLaunchKernelGGL(k_router_comb_bwd<DCH>, grow, blk, 0, st, *b, (int)dgrad_mfma));

@@ -40,7 +40,7 @@ __device__ __forceinline__ void mfma_chunk(const float (*As)[kTK + 1], const flo
 // bin.  The order INSIDE a pattern is whatever the atomics make it: it does not matter, every column's result is its
 // own and is written to the column's own place.
 constexpr int kPatBins = 256, kPermHdr = 512, kSortMinCols = 64;  // (below two tiles there is nothing to sort; the caller decides from where it pays)
-__global__ __launch_bounds__(256) void k_shared_pattern(ic_router_args a, int mode) {
+__global__ __launch_bounds__(256) void k_shared_pattern(ic_router_args a, int mode, const int32_t* bwd_slot) {
   __shared__ int hist[kPatBins];
   const int N = a.S * a.R, n = blockIdx.x * 256 + threadIdx.x;
   hist[threadIdx.x] = 0;
@@ -53,7 +53,9 @@ __global__ __launch_bounds__(256) void k_shared_pattern(ic_router_args a, int mo
         if (prev_on(a, s, a.src[e])) pat |= 1 << a.widx[e];
       pat &= kPatBins - 1;
     } else {
-      pat = prev_on(a, s, r) ? 1 : 0;
+      // (ic_router_bwd_args.in_slot: the stream's block of H / mask_prev, negative = the stream takes no part)
+      if (bwd_slot) pat = bwd_slot[s] >= 0 && a.mask_prev[(size_t)bwd_slot[s] * a.R + r] != 0;
+      else pat = prev_on(a, s, r) ? 1 : 0;
     }
     pat = ~pat & (kPatBins - 1);  // sort key: the complement, so that all-inactive columns come LAST (their tiles only write zeros)
     a.shared_ws[kPermHdr + n] = pat;
@@ -425,11 +427,19 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
   const int d = a.d, N = a.S * a.R;
   const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * kTN;
   __shared__ int tcol[kTN];
+  // stream addressing of the backward (router.hip): stream s lives at index s * sk of the per-stream arrays except
+  // f.H / f.mask_prev / gH, which sit at block in_slot[s] when in_slot is set (negative: the stream takes no part)
+  const int sk = b.sk > 1 ? b.sk : 1;
+  auto sender_on = [&](int s, int r) {
+    if (b.in_slot) return b.in_slot[s] >= 0 && a.mask_prev[(size_t)b.in_slot[s] * a.R + r] != 0;
+    return prev_on(a, s, r);
+  };
   if (tid < kMaxShared) any_k[tid] = 0;
   if (tid < kTN) {  // this tile's columns: in (stream, region) order, or active senders first (sorted permutation)
     int n = col0 + tid;
     if (perm && n < N) n = perm[n];
-    tcol[tid] = (unsigned)n < (unsigned)N ? n : -1;
+    const bool ok = (unsigned)n < (unsigned)N && (!b.in_slot || b.in_slot[n / a.R] >= 0);
+    tcol[tid] = ok ? n : -1;
   }
   __syncthreads();
   {  // per column and matrix: the out-edge of the column's sender, its destination and bias, or -1
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
     float sc = 0.f;
     if (k < a.nW && n >= 0) {
       const int s = n / a.R, r = n % a.R;
-      if (prev_on(a, s, r)) {  // (no in_slot / sk on this path: ic_router_bwd checks)
+      if (sender_on(s, r)) {
         for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
           const int e = b.src_edges[i];
           if (a.widx[e] == k) {
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
 #pragma unroll
   for (int v = 0; v < 16; ++v) hv[v] = 0.f;
   if (n >= 0) {
-    const float* hrow = h_row(a, s_col, r_col);
+    const float* hrow = b.in_slot ? a.H + ((size_t)b.in_slot[s_col] * a.R + r_col) * d : h_row(a, s_col, r_col);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = row0 + wave * 32 + 8 * q + 4 * (lane >> 5);
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
   v16f tot;
 #pragma unroll
   for (int v = 0; v < 16; ++v) tot[v] = 0.f;
-  const int SE = a.S * a.E;
+  const int SE = a.S * sk * a.E;
   for (int k = 0; k < a.nW; ++k) {
     if (!any_k[k]) continue;  // workgroup-uniform
     const float* W = a.W + (size_t)k * d * d;
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
     // B[kk][c] = gM[s, dst][kk0 + kk]; thread -> (column tid / 8, 4 k's); next chunk prefetched into registers
     const int akk = tid >> 3, ai0 = (tid & 7) * 16;
     const int bc = tid >> 3, bks = (tid & 7) * 4, bdst = tdst[k][bc];
-    const float* brow = bdst >= 0 ? b.gM + ((size_t)(tcol[bc] / a.R) * a.R + bdst) * d : nullptr;
+    const float* brow = bdst >= 0 ? b.gM + ((size_t)(tcol[bc] / a.R) * sk * a.R + bdst) * d : nullptr;
     float4 av[4], bv;
     auto fetch = [&](int kk0) {
 #pragma unroll
@@ -527,12 +537,13 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
     if (tid < kTN) {
       const int e = tedge[k][tid], nn = tcol[tid];
       if (e >= 0 && nn >= 0)
-        b.g_ebias_part[(size_t)blockIdx.x * SE + (size_t)(nn / a.R) * a.E + e] = (pb[0][tid] + pb[1][tid]) + (pb[2][tid] + pb[3][tid]);
+        b.g_ebias_part[(size_t)blockIdx.x * SE + (size_t)(nn / a.R) * sk * a.E + e] = (pb[0][tid] + pb[1][tid]) + (pb[2][tid] + pb[3][tid]);
     }
     __syncthreads();
   }
   if (n >= 0) {
-    float* out = b.gH + (size_t)n * d;
+    float* out = b.in_slot ? b.gH + ((size_t)b.in_slot[s_col] * a.R + r_col) * d
+                           : b.gH + (int64_t)s_col * (b.gH_sstride ? b.gH_sstride : (int64_t)a.R * d) + (size_t)r_col * d;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = row0 + wave * 32 + 8 * q + 4 * (lane >> 5);
@@ -545,14 +556,14 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
 
 // The sorted permutation of the columns (mode 0: forward patterns, 1: active senders first) in a->shared_ws, when the
 // caller brought one and the map is large enough for the two small launches to pay; *perm stays null otherwise.
-static int shared_sort(const ic_router_args* a, int mode, hipStream_t st, const int32_t** perm) {
+static int shared_sort(const ic_router_args* a, int mode, const int32_t* bwd_slot, hipStream_t st, const int32_t** perm) {
   const int N = a->S * a->R;
   if (!a->shared_ws || N < kSortMinCols || a->nW > 8) return IC_OK;
   if (hipMemsetAsync(a->shared_ws, 0, kPermHdr * sizeof(int32_t), st) != hipSuccess) {
     ic_set_error("ic_router: hipMemsetAsync of the column-sort counters failed");
     return IC_ELAUNCH;
   }
-  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_shared_pattern, dim3(ic_ceil_div(N, 256)), dim3(256), 0, st, *a, mode));
+  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_shared_pattern, dim3(ic_ceil_div(N, 256)), dim3(256), 0, st, *a, mode, bwd_slot));
   IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_shared_scatter, dim3(ic_ceil_div(N, 256)), dim3(256), 0, st, *a));
   *perm = a->shared_ws + kPermHdr + N;
   return IC_OK;
@@ -563,7 +574,7 @@ int ic_router_shared_fwd_launch(const ic_router_args* a, hipStream_t st) {
   const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->S * a->R, kTN));
   IC_BYTES(IC_KID_router_mfma, 4.0 * ((double)a->nW * a->d * a->d + 2.0 * a->S * a->R * a->d));
   const int32_t* perm = nullptr;
-  if (const int rc = shared_sort(a, 0, st, &perm)) return rc;
+  if (const int rc = shared_sort(a, 0, nullptr, st, &perm)) return rc;
   IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_fwd_mfma, grid, dim3(256), 0, st, *a, perm));
   return IC_OK;
 }
@@ -594,7 +605,7 @@ int ic_router_shared_dgrad_launch(const ic_router_bwd_args* b, int nslab, hipStr
   const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->S * a->R, kTN));
   IC_BYTES(IC_KID_router_mfma, 4.0 * ((double)a->nW * a->d * a->d + 3.0 * a->S * a->R * a->d));
   const int32_t* perm = nullptr;
-  if (const int rc = shared_sort(a, 1, st, &perm)) return rc;
+  if (const int rc = shared_sort(a, 1, b->in_slot, st, &perm)) return rc;
   IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_dgrad_mfma, grid, dim3(256), 0, st, *b, perm));
   return IC_OK;
 }

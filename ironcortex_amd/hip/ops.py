@@ -243,7 +243,10 @@ class Tape:
 # IC_SHARED_SORT=0: the shared-matrix (by_direction) forward GEMM walks its columns in (stream, region) order instead of
 # sorted by activity pattern (A/B timing; same results bit for bit)
 SHARED_SORT = os.environ.get("IC_SHARED_SORT", "1") != "0"
-SHARED_SORT_MIN = int(os.environ.get("IC_SHARED_SORT_MIN", "4096"))  # columns (streams x regions) from which the sort is used
+SHARED_SORT_MIN = int(os.environ.get("IC_SHARED_SORT_MIN", "8192"))  # columns (streams x regions) from which the sort is used
+# IC_SHARED_GEMM_ALWAYS=1: the by_direction forward as a GEMM at any size (IC_RF_SHARED_GEMM); default: the library takes
+# the per-edge kernels below 8192 columns (tests set this to cover the GEMM kernels at oracle-sized inputs)
+SHARED_GEMM_ALWAYS = os.environ.get("IC_SHARED_GEMM_ALWAYS", "0") == "1"
 _SHARED_WS: Dict[tuple, torch.Tensor] = {}
 
 # IC_WGRAD_GEMM=0: the deferred per-edge / per-region weight gradients always through the row-slice kernels (A/B timing)
@@ -468,6 +471,8 @@ class RouterSpec:
 
 def _router_args(spec: RouterSpec, T: Dict[str, torch.Tensor], P: Dict[str, torch.Tensor], S: int):
     flags = (IC_RF_PRECISION if spec.precision else 0) | (ENUMS["IC_RF_SHARED"] if spec.shared_gemm else 0)
+    if spec.shared_gemm and SHARED_GEMM_ALWAYS:
+        flags |= ENUMS["IC_RF_SHARED_GEMM"]
     if spec.factorized:
         flags |= ENUMS["IC_RF_FACTORIZED"]
     a = new("ic_router_args", S=S, R=spec.R, d=spec.d, E=spec.E, flags=flags, nW=spec.nW)

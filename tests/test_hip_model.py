@@ -112,6 +112,32 @@ def test_two_train_steps_vs_reference(name, engine):
     PL.flush(tag)
 
 
+@pytest.mark.parametrize("name", ["bydir", "factorized"])
+def test_shared_modes_engine_backward_on_mfma_dgrad(name):
+    """The LoopEngine's batched backward addresses its streams through in_slot / sk; the shared-matrix modes' input
+    gradient must run on the MFMA GEMM there too (k_router_shared_dgrad_mfma), not on the per-edge transposed GEMVs +
+    gather (the gradients themselves are compared with the reference's in test_two_train_steps_vs_reference)."""
+    import ironcortex_amd as ic
+    from ironcortex_amd import hip
+    if name not in SHARED_CASES:
+        pytest.skip(f"no case {name}")
+    gold, cfg, sd, tokens, focus = load_case(name)
+    model = build(cfg, sd)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    seed_train()
+    hip.prof_select("")
+    hip.prof_enable(True)
+    hip.prof_read()
+    try:
+        ic.train_step(model, opt, tokens.to(DEV), ic.LossWeights(), torch.device(DEV))
+        torch.cuda.synchronize()
+        prof = hip.prof_read()
+    finally:
+        hip.prof_enable(False)
+    assert prof.get("router_mfma", (0, 0))[0] > 0, sorted(prof)
+    assert "router_mat_bwd" not in prof and "router_gather_bwd" not in prof, sorted(prof)
+
+
 def test_checkpoint_roundtrip(tmp_path):
     """reference tests/test_checkpoint.py: bit-equal state after save/load, keys unchanged."""
     import ironcortex_amd as ic

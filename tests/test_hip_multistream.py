@@ -143,7 +143,7 @@ def test_train_step_multi_mode_runs_and_strict_is_untouched():
         assert out["strict"][k] == pytest.approx(float(gold[f"step0.{k}"]), rel=2e-5, abs=1e-6), k
 
 
-@pytest.mark.parametrize("variant", ["by_direction", "groups"])
+@pytest.mark.parametrize("variant", ["by_direction", "by_direction_edge_kernels", "groups"])
 def test_multistream_by_direction_and_launch_groups(variant, monkeypatch):
     """Two corners of the lockstep path, each stream again against an oracle batch-1 run from the same warmed state:
     the shared-matrix router (edge_transform_mode="by_direction": the MFMA forward reads each stream's parent block
@@ -153,8 +153,12 @@ def test_multistream_by_direction_and_launch_groups(variant, monkeypatch):
     from ironcortex_amd.config import CortexConfig
     from tests.model_cases import MODEL_CASES
     kw = dict(MODEL_CASES["default"])
-    if variant == "by_direction":
+    if variant.startswith("by_direction"):
         kw["edge_transform_mode"] = "by_direction"
+        # the GEMM at this size only when asked for (IC_RF_SHARED_GEMM); the library's own choice below 8192 columns is
+        # the per-edge kernels reading the shared matrices through widx (second variant)
+        from ironcortex_amd.hip import ops
+        monkeypatch.setattr(ops, "SHARED_GEMM_ALWAYS", variant == "by_direction")
     cfg = CortexConfig(**kw)
     torch.manual_seed(5)
     ref = ic.CortexReasoner(ic.hex_neighbors(cfg.R), ic.hex_axial_coords(cfg.R), {"sensor": 0, "motor": cfg.R - 1}, cfg)

@@ -273,15 +273,19 @@ def test_router_forward_many_streams_equals_stream_groups_bitwise(d):
     assert torch.equal(whole, parts)
 
 
+@pytest.mark.parametrize("gemm", [True, False], ids=["gemm", "per-edge-kernels"])
 @pytest.mark.parametrize("R,S,d", [(36, 4, 256), (64, 8, 256), (10, 3, 48)])
-def test_router_by_direction_mfma_vs_oracle(R, S, d):
+def test_router_by_direction_mfma_vs_oracle(R, S, d, gemm, monkeypatch):
     """edge_transform_mode="by_direction" (gate.py:142-149,274-277): the forward is ONE fp32-MFMA GEMM
-    [d, 6d] x [6d, S*R] (k_router_shared_fwd_mfma), the shared matrices' gradient one deterministic MFMA GEMM
-    per direction (k_wgrad_shared_mfma, no float atomics) -- against the per-stream oracle, and bit-identical
-    from run to run."""
+    [d, 6d] x [6d, S*R] (k_router_shared_fwd_mfma; at these sizes only when asked for, IC_RF_SHARED_GEMM -- by default
+    the library serves fewer than 8192 columns with the per-edge kernels reading W[widx[e]], the second variant), the
+    shared matrices' gradient one deterministic MFMA GEMM per direction (k_wgrad_shared_mfma, no float atomics) --
+    against the per-stream oracle, and bit-identical from run to run."""
     from ironcortex_amd.gate import Router
+    from ironcortex_amd.hip import ops
     from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
     from oracle import hotpath as O
+    monkeypatch.setattr(ops, "SHARED_GEMM_ALWAYS", gemm)
     seed = 7900 + R + S
     nb = hex_neighbors(R)
     coords = hex_axial_coords(R)
@@ -313,7 +317,7 @@ def test_router_by_direction_mfma_vs_oracle(R, S, d):
     Hc = H.clone().requires_grad_(True)
     Mc = torch.stack([O.router_messages(P, Hc[s], mask[s], coords, nb, mode="by_direction")[0] for s in range(S)])
     (Mc * gM).sum().backward()
-    _TAG[0] = f"by_direction-mfma/R{R}/S{S}/d{d}"
+    _TAG[0] = f"by_direction-{'mfma' if gemm else 'edge-kernels'}/R{R}/S{S}/d{d}"
     close(M, Mc, what="M")
     gclose(gH, Hc.grad, what="g.H")
     gclose(router.beta_cos.grad, P["beta_cos"].grad, what="g.beta_cos")
@@ -325,7 +329,7 @@ def test_router_by_direction_mfma_vs_oracle(R, S, d):
 
 @pytest.mark.parametrize("R,S,d,p_on", [(128, 32, 64, 0.3), (100, 41, 48, 0.06), (256, 16, 256, 0.0625)])
 def test_router_by_direction_sorted_columns(R, S, d, p_on, monkeypatch):
-    """From 4096 columns on, the shared-matrix forward GEMM walks its columns sorted by activity pattern
+    """With a workspace (ops: from 8192 columns on; here from 4096), the shared-matrix forward GEMM walks its columns sorted by activity pattern
     (k_shared_pattern / k_shared_scatter, ic_router_args.shared_ws), so that a 32-column tile multiplies only the
     direction matrices its columns use, and the data-gradient GEMM walks the active senders first.  Every column's
     result is its own: outputs and gradients must equal the unsorted kernels' bit for bit (twice in a row: the workspace header is cleared per call), and the oracle's on sampled
@@ -335,6 +339,8 @@ def test_router_by_direction_sorted_columns(R, S, d, p_on, monkeypatch):
     from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
     from oracle import hotpath as O
     seed = 8100 + R + S
+    monkeypatch.setattr(ops, "SHARED_GEMM_ALWAYS", True)  # (the library's own choice starts at 8192 columns)
+    monkeypatch.setattr(ops, "SHARED_SORT_MIN", 4096)
     nb = hex_neighbors(R)
     coords = hex_axial_coords(R)
     router = Router(nb, d, R, edge_transform_mode="by_direction").to(DEV)
@@ -445,6 +451,7 @@ def test_router_factorized_sorted_columns(R, S, d, p_on, monkeypatch):
     from ironcortex_amd.hip import ops
     from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
     seed = 8300 + R + S
+    monkeypatch.setattr(ops, "SHARED_SORT_MIN", 4096)
     router = Router(hex_neighbors(R), d, R, edge_transform_mode="factorized").to(DEV)
     assert router.fact_lib
     monkeypatch.setattr(router, "_route_factorized", None)
