@@ -110,23 +110,23 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
     tcol[tid] = (unsigned)n < (unsigned)N ? n : -1;
   }
   __syncthreads();
-  {  // per column and shared matrix: the sender row and bias of the (unique) active in-edge, or -1
-    const int c = tid & 31, k = tid >> 5, n = tcol[c];
-    int srow = -1;
-    float sc = 0.f;
-    if (k < a.nW && n >= 0) {
+  {  // per column and shared matrix: the sender row and bias of the (unique) active in-edge, or -1.  One thread per
+     // (column, in-edge slot): the tables of all of a column's edges are read in ONE round of dependent loads
+    const int c = tid & 31, i = tid >> 5, n = tcol[c];
+    tsrc[i][c] = -1;
+    tscale[i][c] = 0.f;
+    __syncthreads();
+    if (n >= 0) {
       const int s = n / a.R, r = n % a.R;
-      for (int e = a.dst_off[r]; e < a.dst_off[r + 1]; ++e) {
-        if (a.widx[e] == k && prev_on(a, s, a.src[e])) {
-          srow = a.src[e];
-          sc = a.ebias[e];
-          break;
+      for (int e = a.dst_off[r] + i; e < a.dst_off[r + 1]; e += kMaxShared) {
+        const int k = a.widx[e], sr = a.src[e];
+        if (k >= 0 && k < a.nW && prev_on(a, s, sr)) {
+          tsrc[k][c] = sr;
+          tscale[k][c] = a.ebias[e];
+          any_k[k] = 1;  // (same value from every writer)
         }
       }
     }
-    tsrc[k][c] = srow;
-    tscale[k][c] = sc;
-    if (srow >= 0) any_k[k] = 1;  // (same value from every writer)
   }
   __syncthreads();
   v16f acc;
@@ -442,33 +442,31 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
     tcol[tid] = ok ? n : -1;
   }
   __syncthreads();
-  {  // per column and matrix: the out-edge of the column's sender, its destination and bias, or -1
-    const int c = tid & 31, k = tid >> 5, n = tcol[c];
-    int dst = -1, edge = -1;
-    float sc = 0.f;
-    if (k < a.nW && n >= 0) {
+  {  // per column and matrix: the out-edge of the column's sender, its destination and bias, or -1.  One thread per
+     // (column, out-edge slot), so that the tables of a sender's edges are read in one round of dependent loads
+    const int c = tid & 31, i = tid >> 5, n = tcol[c];
+    tdst[i][c] = -1;
+    tedge[i][c] = -1;
+    tscale[i][c] = 0.f;
+    __syncthreads();
+    if (n >= 0) {
       const int s = n / a.R, r = n % a.R;
       if (sender_on(s, r)) {
-        for (int i = b.src_off[r]; i < b.src_off[r + 1]; ++i) {
-          const int e = b.src_edges[i];
-          if (a.widx[e] == k) {
-            edge = e;
-            sc = a.ebias[e];
-            int lo = 0, hi = a.R;  // destination of e: the r' with dst_off[r'] <= e < dst_off[r'+1]
-            while (hi - lo > 1) {
-              const int mid = (lo + hi) >> 1;
-              if (a.dst_off[mid] <= e) lo = mid; else hi = mid;
-            }
-            dst = lo;
-            break;
+        for (int q = b.src_off[r] + i; q < b.src_off[r + 1]; q += kMaxShared) {
+          const int e = b.src_edges[q], k = a.widx[e];
+          if (k < 0 || k >= a.nW) continue;
+          int lo = 0, hi = a.R;  // destination of e: the r' with dst_off[r'] <= e < dst_off[r'+1]
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.dst_off[mid] <= e) lo = mid; else hi = mid;
           }
+          tdst[k][c] = lo;
+          tedge[k][c] = e;
+          tscale[k][c] = a.ebias[e];
+          any_k[k] = 1;
         }
       }
     }
-    tdst[k][c] = dst;
-    tedge[k][c] = edge;
-    tscale[k][c] = sc;
-    if (dst >= 0) any_k[k] = 1;
   }
   __syncthreads();
   const int j = lane & 31, n = tcol[j];
