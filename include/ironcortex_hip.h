@@ -56,8 +56,8 @@ enum {
 enum {
   IC_RF_PRECISION = 1 << 0, /* enable_precision_routed_messages (gate.py:292-318) */
   IC_RF_SHARED = 1 << 1,    /* widx selects one of nW <= 8 matrices SHARED by many edges (edge_transform_mode
-                               "by_direction", gate.py:142-149,274-277) and no destination has two incoming edges
-                               with the same widx: without IC_RF_PRECISION the forward then runs as ONE GEMM
+                               "by_direction", gate.py:142-149,274-277), no destination has two incoming edges
+                               and no sender two outgoing edges with the same widx: without IC_RF_PRECISION the forward then runs as ONE GEMM
                                [d, nW*d] x [nW*d, S*R] on the matrix cores (fp32 MFMA) instead of per-edge GEMVs --
                                from 8192 (stream, region) columns on: below, a tile's nW back-to-back K loops are a
                                latency chain (~50 us at d=256) that the per-edge kernels, reading W[widx[e]] in place

@@ -92,30 +92,35 @@ __global__ __launch_bounds__(256) void k_shared_scatter(ic_router_args a) {
   }
 }
 
+// NB 32-column blocks per workgroup: the A chunk (rows of W_k) staged once in LDS and its fragment read once from LDS
+// serves NB MFMAs, one per column block.  Same sums per column whatever NB.
+template <int NB>
 __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a, const int32_t* perm) {
+  constexpr int TN = kTN * NB;
   __shared__ float As[kTM][kTK + 1];
-  __shared__ float Bs[kTK][kTN + 1];
-  __shared__ int tsrc[kMaxShared][kTN];
-  __shared__ float tscale[kMaxShared][kTN];
+  __shared__ float Bs[kTK][TN + 1];
+  __shared__ int tsrc[kMaxShared][TN];
+  __shared__ float tscale[kMaxShared][TN];
   __shared__ int any_k[kMaxShared];
+  __shared__ int tcol[TN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = a.d, N = a.S * a.R;
-  const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * kTN;
+  const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * TN;
   if (tid < kMaxShared) any_k[tid] = 0;
-  __syncthreads();
-  __shared__ int tcol[kTN];
-  if (tid < kTN) {  // this tile's columns: in (stream, region) order, or through the sorted permutation
+  if (tid < TN) {  // this tile's columns: in (stream, region) order, or through the sorted permutation
     int n = col0 + tid;
     if (perm && n < N) n = perm[n];
     tcol[tid] = (unsigned)n < (unsigned)N ? n : -1;
   }
+  for (int idx = tid; idx < kMaxShared * TN; idx += 256) {
+    tsrc[idx / TN][idx % TN] = -1;
+    tscale[idx / TN][idx % TN] = 0.f;
+  }
   __syncthreads();
-  {  // per column and shared matrix: the sender row and bias of the (unique) active in-edge, or -1.  One thread per
-     // (column, in-edge slot): the tables of all of a column's edges are read in ONE round of dependent loads
-    const int c = tid & 31, i = tid >> 5, n = tcol[c];
-    tsrc[i][c] = -1;
-    tscale[i][c] = 0.f;
-    __syncthreads();
+  // per column and shared matrix: the sender row and bias of the (unique) active in-edge, or -1.  One thread per
+  // (column, in-edge slot): the tables of all of a column's edges are read in ONE round of dependent loads
+  for (int idx = tid; idx < kMaxShared * TN; idx += 256) {
+    const int c = idx % TN, i = idx / TN, n = tcol[c];
     if (n >= 0) {
       const int s = n / a.R, r = n % a.R;
       for (int e = a.dst_off[r] + i; e < a.dst_off[r + 1]; e += kMaxShared) {
@@ -129,27 +134,37 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
     }
   }
   __syncthreads();
-  v16f acc;
+  v16f acc[NB];
 #pragma unroll
-  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
   for (int k = 0; k < a.nW; ++k) {
     if (!any_k[k]) continue;  // workgroup-uniform
     const float* W = a.W + (size_t)k * d * d;
     // A: rows row0.. of W_k, columns kk0..kk0+31; thread -> (row tid / 2, 16 columns)
-    // B: the gathered, bias-scaled sender rows; thread -> (column tid / 8, 4 k's)
+    // B: the gathered, bias-scaled sender rows; thread -> (column tid / 8 of every block, 4 k's)
     // The next chunk's operands are requested into registers before the current chunk's MFMAs run.
     const int ar = tid >> 1, ah = (tid & 1) * 16, agrow = row0 + ar;
-    const int bc = tid >> 3, bks = (tid & 7) * 4, bsrow = tsrc[k][bc];
-    const float bsc = tscale[k][bc];
-    const float* brow = bsrow >= 0 ? h_row(a, tcol[bc] / a.R, bsrow) : nullptr;
-    float4 av[4], bv;
+    const int bc = tid >> 3, bks = (tid & 7) * 4;
+    float bsc[NB];
+    const float* brow[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int c = nb * kTN + bc, bsrow = tsrc[k][c];
+      bsc[nb] = tscale[k][c];
+      brow[nb] = bsrow >= 0 ? h_row(a, tcol[c] / a.R, bsrow) : nullptr;
+    }
+    float4 av[4], bv[NB];
     auto fetch = [&](int kk0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int kk = kk0 + ah + 4 * q;
         av[q] = (agrow < d && kk < d) ? *reinterpret_cast<const float4*>(W + (size_t)agrow * d + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      bv = (brow && kk0 + bks < d) ? *reinterpret_cast<const float4*>(brow + kk0 + bks) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        bv[nb] = (brow[nb] && kk0 + bks < d) ? *reinterpret_cast<const float4*>(brow[nb] + kk0 + bks) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     fetch(0);
     for (int kk0 = 0; kk0 < d; kk0 += kTK) {
@@ -157,19 +172,34 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
       for (int q = 0; q < 4; ++q) {
         As[ar][ah + 4 * q + 0] = av[q].x; As[ar][ah + 4 * q + 1] = av[q].y; As[ar][ah + 4 * q + 2] = av[q].z; As[ar][ah + 4 * q + 3] = av[q].w;
       }
-      Bs[bks + 0][bc] = bv.x * bsc; Bs[bks + 1][bc] = bv.y * bsc; Bs[bks + 2][bc] = bv.z * bsc; Bs[bks + 3][bc] = bv.w * bsc;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int c = nb * kTN + bc;
+        Bs[bks + 0][c] = bv[nb].x * bsc[nb]; Bs[bks + 1][c] = bv[nb].y * bsc[nb]; Bs[bks + 2][c] = bv[nb].z * bsc[nb]; Bs[bks + 3][c] = bv[nb].w * bsc[nb];
+      }
       __syncthreads();
       if (kk0 + kTK < d) fetch(kk0 + kTK);
-      mfma_chunk(As, Bs, wave, lane, acc);
+      {
+        const int ai = wave * 32 + (lane & 31), kh = lane >> 5, bj = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < kTK; kk += 2) {
+          const float af = As[ai][kk + kh];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, Bs[kk + kh][nb * kTN + bj], acc[nb], 0, 0, 0);
+        }
+      }
       __syncthreads();
     }
   }
-  const int j = lane & 31, n = tcol[j];
-  if (n >= 0) {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int i = row0 + wave * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
-      if (i < d) a.M[(size_t)n * d + i] = acc[v];
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = tcol[nb * kTN + (lane & 31)];
+    if (n >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = row0 + wave * 32 + 8 * q + 4 * (lane >> 5);
+        if (i < d) *reinterpret_cast<float4*>(a.M + (size_t)n * d + i) = make_float4(acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
+      }
     }
   }
 }
@@ -569,11 +599,14 @@ static int shared_sort(const ic_router_args* a, int mode, const int32_t* bwd_slo
 
 // library-internal launchers (router.hip: ic_router_fwd / ic_router_wgrad)
 int ic_router_shared_fwd_launch(const ic_router_args* a, hipStream_t st) {
-  const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->S * a->R, kTN));
   IC_BYTES(IC_KID_router_mfma, 4.0 * ((double)a->nW * a->d * a->d + 2.0 * a->S * a->R * a->d));
   const int32_t* perm = nullptr;
   if (const int rc = shared_sort(a, 0, nullptr, st, &perm)) return rc;
-  IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_fwd_mfma, grid, dim3(256), 0, st, *a, perm));
+  static const int nb_env = [] { const char* e = getenv("IC_SHARED_NB"); return e && e[0] ? atoi(e) : 0; }();
+  const int nb = nb_env == 1 || nb_env == 2 ? nb_env : 1;
+  const dim3 grid(ic_ceil_div(a->d, kTM), ic_ceil_div(a->S * a->R, kTN * nb));
+  if (nb == 2) IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_fwd_mfma<2>, grid, dim3(256), 0, st, *a, perm));
+  else IC_TIMED(IC_KID_router_mfma, st, hipLaunchKernelGGL(k_router_shared_fwd_mfma<1>, grid, dim3(256), 0, st, *a, perm));
   return IC_OK;
 }
 

@@ -202,10 +202,12 @@ class Router(FastAttrs, nn.Module):
         if deg > 8:
             raise ValueError("Router: at most 8 incoming edges per region are supported")
         i32 = lambda x: torch.tensor(x if len(x) else [0], dtype=torch.int32, device=dev)
-        # shared matrices as ONE GEMM (IC_RF_SHARED): needs every destination's incoming edges to use distinct
-        # matrices (true on a hex map: one neighbour per direction); otherwise the per-edge GEMV kernel
+        # shared matrices as ONE GEMM (IC_RF_SHARED): needs every destination's incoming edges -- and, for the input
+        # gradient's GEMM over the senders, every sender's outgoing edges -- to use distinct matrices (true on a hex
+        # map: one neighbour per direction); otherwise the per-edge GEMV kernels
         self._shared_gemm = (self.edge_transform_mode == "by_direction" and E > 0 and all(
-            len({widx[e] for e in range(dst_off[r], dst_off[r + 1])}) == dst_off[r + 1] - dst_off[r] for r in range(R)))
+            len({widx[e] for e in range(dst_off[r], dst_off[r + 1])}) == dst_off[r + 1] - dst_off[r] for r in range(R))
+            and all(len({widx[e] for e in out_edges[r]}) == len(out_edges[r]) for r in range(R)))
         self._tables = {"dst_off": i32(dst_off), "src": i32(src), "widx": i32(widx), "src_off": i32(src_off),
                         "src_edges": i32(src_edges), "dst_of_edge": i32(dst),
                         "widx_long": torch.tensor(widx if E else [0], dtype=torch.long, device=dev)}
