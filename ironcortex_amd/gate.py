@@ -211,6 +211,10 @@ class Router(FastAttrs, nn.Module):
         self._tables = {"dst_off": i32(dst_off), "src": i32(src), "widx": i32(widx), "src_off": i32(src_off),
                         "src_edges": i32(src_edges), "dst_of_edge": i32(dst),
                         "widx_long": torch.tensor(widx if E else [0], dtype=torch.long, device=dev)}
+        if E > 0 and len(set(widx)) != E:  # shared parameters: the edges of every parameter, in edge order, padded with E
+            groups = [[e for e in range(E) if widx[e] == k] for k in range(self.nW)]
+            width = max(len(g_) for g_ in groups)
+            self._tables["edges_by_w"] = torch.tensor([g_ + [E] * (width - len(g_)) for g_ in groups], dtype=torch.long, device=dev)
         if self.edge_transform_mode == "factorized":  # identity edge tables of the two shared-matrix row GEMMs
             self._tables.update(iota=i32(list(range(R + 1))), zero=i32([0] * R), ones=torch.ones(R, device=dev))
         self._tables_key = key
@@ -272,7 +276,16 @@ class Router(FastAttrs, nn.Module):
                 "query_W": f.stacked("query_W")}
 
     def _grad_sink(self, name: str, rows: torch.Tensor, widx: torch.Tensor) -> None:
-        self._flat.stacked_grad(name).index_add_(0, widx, rows)
+        """Per-edge gradient rows [E, d] into the stacked gradient of the parameters they index through widx.  One
+        parameter per edge: a scatter without collisions.  Shared parameters (by_direction: raw_P of a direction is
+        used by every edge of that direction): a gather of each parameter's edges in edge order and a sum over them --
+        index_add_ would add colliding rows with atomics, in an order that changes from run to run."""
+        by_w = self._tables.get("edges_by_w") if self._tables else None
+        if by_w is None or rows.shape[0] != self.E:
+            self._flat.stacked_grad(name).index_add_(0, widx, rows)
+            return
+        padded = torch.cat([rows, rows.new_zeros(1, rows.shape[1])])  # (index E: the empty places of the table)
+        self._flat.stacked_grad(name).add_(padded[by_w].sum(1))
 
     def _launch_wgrad(self):
         """End of a backward pass, phase 1: the deferred dW / dKey / dQuery launches; returns the device-side

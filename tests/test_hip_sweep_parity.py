@@ -327,6 +327,68 @@ def test_router_by_direction_mfma_vs_oracle(R, S, d, gemm, monkeypatch):
     PL.flush(_TAG[0])
 
 
+@pytest.mark.parametrize("R,S,d", [(36, 4, 256), (10, 3, 48)])
+def test_router_by_direction_precision_vs_oracle(R, S, d):
+    """by_direction WITH precision routing (gate.py:274-277 with :292-318): messages and keys through the six shared
+    matrices (the per-edge precision kernels read W[widx[e]] / key_W[widx[e]] / raw_P[widx[e]] in place), per-region
+    queries, softmax-combined per destination -- output and every gradient against the per-stream oracle, bit-identical
+    from run to run."""
+    from ironcortex_amd.gate import Router
+    from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
+    from oracle import hotpath as O
+    seed = 8500 + R + S
+    nb = hex_neighbors(R)
+    coords = hex_axial_coords(R)
+    router = Router(nb, d, R, edge_transform_mode="by_direction", enable_precision_routed_messages=True).to(DEV)
+    W_dir, K_dir = gi.det(seed + 1, 6, d, d, kind="xavier"), gi.det(seed + 2, 6, d, d, kind="xavier")
+    Q = gi.det(seed + 3, R, d, d, kind="xavier")
+    rawP = gi.det(seed + 4, 6, d, scale=0.5)
+    t = dict(W_reg=gi.det(seed + 5, 8, 2), beta_cos=gi.det(seed + 6, 8, scale=0.3), beta_sin=gi.det(seed + 7, 8, scale=0.3))
+    with torch.no_grad():
+        router._flat.stacked("W").copy_(W_dir); router._flat.stacked("key_W").copy_(K_dir)
+        router._flat.stacked("query_W").copy_(Q); router._flat.stacked("raw_P").copy_(rawP)
+        router.W_reg.copy_(t["W_reg"]); router.beta_cos.copy_(t["beta_cos"]); router.beta_sin.copy_(t["beta_sin"])
+    mask = gi.det(seed + 8, S, R, kind="rand") < 0.45
+    mask[S - 1] = False
+    H = gi.det(seed + 9, S, R, d) * mask.unsqueeze(-1)
+    gM = gi.det(seed + 10, S, R, d)
+    runs = []
+    for _ in range(2):
+        for p in router.parameters():
+            p.grad = None
+        Hg = H.to(DEV).requires_grad_(True)
+        M = router.route(Hg, mask.to(torch.uint8).to(DEV), coords.to(DEV))
+        (M * gM.to(DEV)).sum().backward()
+        zero = lambda x: x.grad.clone() if x.grad is not None else torch.zeros_like(x)
+        runs.append((M.detach().clone(), Hg.grad.clone(), torch.stack([zero(l.weight) for l in router.W_dir]),
+                     torch.stack([zero(l.weight) for l in router.key_lin_dir]), torch.stack([zero(l.weight) for l in router.query_lin]),
+                     torch.stack([zero(p_) for p_ in router.raw_P_dir]), router.beta_cos.grad.clone(), router.beta_sin.grad.clone()))
+    for a_, b_ in zip(runs[0], runs[1]):
+        assert torch.equal(a_, b_), "not reproducible from run to run"
+    M, gH, gW, gK, gQ, gP, gbc, gbs = runs[0]
+    assert torch.all(M[S - 1] == 0) and float(M.abs().sum()) > 0
+    leaf = lambda x: x.clone().requires_grad_(True)
+    P = {"W_dir": [leaf(W_dir[k]) for k in range(6)], "key_W": [leaf(K_dir[k]) for k in range(6)], "raw_P": [leaf(rawP[k]) for k in range(6)],
+         "query_W": [leaf(Q[r]) for r in range(R)], "W_reg": t["W_reg"], "beta_cos": leaf(t["beta_cos"]), "beta_sin": leaf(t["beta_sin"])}
+    Hc = H.clone().requires_grad_(True)
+    Mc = torch.stack([O.router_messages(P, Hc[s], mask[s], coords, nb, mode="by_direction", precision=True)[0] for s in range(S)])
+    (Mc * gM).sum().backward()
+    z = lambda xs: torch.stack([x.grad if x.grad is not None else torch.zeros_like(x) for x in xs])
+    _TAG[0] = f"by_direction-precision/R{R}/S{S}/d{d}"
+    close(M, Mc, what="M")
+    gclose(gH, Hc.grad, what="g.H")
+    gclose(gW, z(P["W_dir"]), what="g.W_dir")
+    # keys / queries / precisions: relative to the largest entry of the whole stack (a destination with ONE active
+    # in-edge has a softmax over one logit: its query and key gradients are analytically zero, rounding noise on both sides)
+    flat = lambda x: x.reshape(1, -1)
+    close(flat(gK), flat(z(P["key_W"])), what="g.key_W", tol=1e-4)
+    close(flat(gQ), flat(z(P["query_W"])), what="g.query_W", tol=1e-4)
+    close(flat(gP), flat(z(P["raw_P"])), what="g.raw_P", tol=1e-4)
+    gclose(gbc, P["beta_cos"].grad, what="g.beta_cos")
+    gclose(gbs, P["beta_sin"].grad, what="g.beta_sin")
+    PL.flush(_TAG[0])
+
+
 @pytest.mark.parametrize("R,S,d,p_on", [(128, 32, 64, 0.3), (100, 41, 48, 0.06), (256, 16, 256, 0.0625)])
 def test_router_by_direction_sorted_columns(R, S, d, p_on, monkeypatch):
     """With a workspace (ops: from 8192 columns on; here from 4096), the shared-matrix forward GEMM walks its columns sorted by activity pattern
