@@ -32,7 +32,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROF_STRIDE = 8        # the dominant kernel's launches are event-bracketed 1 in 8 in the measurement pass after the timed region
+PROF_STRIDE = 7        # the dominant kernel's launches are event-bracketed 1 in 7 in the measurement pass after the timed region
+                       # (coprime with K_inner = 8 and with the 3 GEMV launches per iteration: a stride of 8 sampled the SAME
+                       # iteration of every loop -- at R=512 the first one, whose router has no active sender yet)
 EVENT_STEPS = 3        # steps of that pass
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
