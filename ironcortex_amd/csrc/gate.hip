@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void k_gate_scores(ic_gate_args a) {
 
 // One workgroup per stream.
 constexpr int kGateLdsNbr = 6144;  // a hex map of 1024 regions
-__global__ __launch_bounds__(256) void k_gate_select(ic_gate_args a) {
+// (256 threads, or 1024 on maps above 256 regions: one region per thread in the selection rounds of ic_gate.h)
+__global__ __launch_bounds__(1024) void k_gate_select(ic_gate_args a) {
   __shared__ __align__(16) float sc[1024];
   __shared__ int order[1024];
   __shared__ uint8_t supp[1024];
@@ -193,7 +194,7 @@ extern "C" int ic_gate_select(const ic_gate_args* a, ic_stream_t stream) {
   IC_REQUIRE(!a->force_io || (a->sensor_idx >= 0 && a->sensor_idx < a->R && a->motor_idx >= 0 &&
                               a->motor_idx < a->R),
              "ic_gate_select: io indices out of range");
-  IC_TIMED(IC_KID_gate_select, (hipStream_t)stream, hipLaunchKernelGGL(k_gate_select, dim3(a->S), dim3(256), 0, (hipStream_t)stream, *a));
+  IC_TIMED(IC_KID_gate_select, (hipStream_t)stream, hipLaunchKernelGGL(k_gate_select, dim3(a->S), dim3(a->R > 512 ? 1024 : (a->R > 256 ? 512 : 256)), 0, (hipStream_t)stream, *a));
   IC_LAUNCH_CHECK("ic_gate_select");
   return IC_OK;
 }

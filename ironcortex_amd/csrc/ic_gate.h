@@ -37,7 +37,156 @@ __device__ __forceinline__ void gate_select_body(const ic_gate_args& a, int s, f
   }
   big_deg = __syncthreads_or(big_deg);
   if (l_off && R > 64) {
-    // Large maps: the same total order (score descending, index ascending) from a bitonic sorting network over
+    // Large maps with a SYMMETRIC adjacency (checked here, in LDS; hex maps are): no ranking and no walk.  The walk of
+    // utils.py:115-123 selects the lexicographically first maximal independent set in the total order (score
+    // descending, index ascending), cut after max(k, 1) selections.  Membership of a region depends only on its
+    // better-placed neighbours, so the set comes out of parallel rounds: an undecided region with a selected neighbour
+    // is suppressed; one with no undecided better-placed neighbour is selected (two adjacent regions never both are:
+    // the order is total).  Random scores settle in O(log R) rounds of one LDS pass each; a monotone ridge of scores
+    // needs as many rounds as it is long, still one pass each.  The selections in the order of the walk are the
+    // members by rank AMONG THE MEMBERS (a third of the map at most on a hex map): counted only if more than the
+    // limit exist.  R = 512, 32 selections: 45 -> ~12 us per launch.
+    int asym = 0;
+    for (int i = threadIdx.x; i < R; i += blockDim.x)
+      for (int q = l_off[i]; q < l_off[i + 1]; ++q) {
+        const int j = l_nbr[q];
+        bool back = false;
+        for (int q2 = l_off[j]; q2 < l_off[j + 1]; ++q2) back |= l_nbr[q2] == i;
+        asym |= !back;
+      }
+    if (!__syncthreads_or(asym)) {
+      const int kt = a.k_total_s ? a.k_total_s[s] : a.k_total;
+      if (kt == IC_GATE_OFF) return;  // (workgroup-uniform; the mask stays empty)
+      uint8_t* mask = a.mask + s * R;
+      int k = kt > 0 ? kt : 0;
+      if (a.force_io) {  // gate.py:80-84
+        if (threadIdx.x == 0) {
+          mask[a.sensor_idx] = 1;
+          mask[a.motor_idx] = 1;
+        }
+        k = k - 2 > 0 ? k - 2 : 0;
+      }
+      const int limit = k > 1 ? k : 1;  // (utils.py:118-120: the count is tested after the append)
+      auto better = [&](int j, int i) { return sc[j] > sc[i] || (sc[j] == sc[i] && j < i); };
+      __shared__ int n_mem_s;
+      __shared__ __align__(16) float msc[1024 + 4];
+      __shared__ __align__(16) int mid[1024 + 4];
+      int undecided;
+      if ((int)blockDim.x >= R && !big_deg) {
+        // One region per thread, its <= 8 neighbours and which of them are better placed held in registers: a round is
+        // eight independent LDS reads of neighbour states and two barriers.
+        const int i = threadIdx.x;
+        const bool live = i < R;
+        const float sci = live ? sc[i] : 0.f;
+        unsigned int nbp[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, bm = 0;
+        int deg = 0;
+        if (live) {
+          const int o0 = l_off[i];
+          deg = l_off[i + 1] - o0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (q < deg) {
+              const unsigned int j = l_nbr[o0 + q];
+              nbp[q >> 1] = (q & 1) ? ((nbp[q >> 1] & 0xFFFFu) | (j << 16)) : ((nbp[q >> 1] & 0xFFFF0000u) | j);
+              bm |= (unsigned int)better((int)j, i) << q;
+            }
+        }
+        int my = live ? 0 : 2;  // 0 undecided, 1 selected, 2 suppressed (also in supp[i], for the neighbours)
+        if (threadIdx.x == 0) n_mem_s = 0;
+        do {
+          int ns = 3, left = 0;
+          if (my == 0) {
+            bool win = true, dead = false;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (q < deg) {
+                const uint8_t st = supp[(nbp[q >> 1] >> (16 * (q & 1))) & 0xFFFFu];
+                dead |= st == 1;
+                win &= !(st == 0 && ((bm >> q) & 1u));
+              }
+            ns = dead ? 2 : (win ? 1 : 0);
+            left = ns == 0;
+          }
+          __syncthreads();  // every state of this round has been read
+          if (ns == 1 || ns == 2) {
+            supp[i] = (uint8_t)ns;
+            my = ns;
+          }
+          undecided = __syncthreads_or(left);
+        } while (undecided);
+        if (my == 1) {  // the members in any order; each one's rank among them only if the limit cuts
+          const int t = atomicAdd(&n_mem_s, 1);
+          mid[t] = i;
+          msc[t] = sci;
+        }
+        __syncthreads();
+        const int M = n_mem_s;
+        if (M <= limit) {
+          if (my == 1) mask[i] = 1;
+          return;
+        }
+        if (threadIdx.x < 4) {  // pad to a multiple of four: pairs that sort behind every member
+          msc[M + threadIdx.x] = -INFINITY;
+          mid[M + threadIdx.x] = 0x7FFFFFFF;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < M) {  // member t by thread t (the first waves only), four members per LDS read
+          const int me = mid[threadIdx.x];
+          const float v = msc[threadIdx.x];
+          const float4* s4 = reinterpret_cast<const float4*>(msc);
+          const int4* i4 = reinterpret_cast<const int4*>(mid);
+          int rank = 0;
+#pragma unroll 2
+          for (int u = 0; u < (M + 3) / 4; ++u) {
+            const float4 f = s4[u];
+            const int4 d4 = i4[u];
+            rank += (f.x > v) | ((f.x == v) & (d4.x < me));
+            rank += (f.y > v) | ((f.y == v) & (d4.y < me));
+            rank += (f.z > v) | ((f.z == v) & (d4.z < me));
+            rank += (f.w > v) | ((f.w == v) & (d4.w < me));
+          }
+          if (rank < limit) mask[me] = 1;
+        }
+        return;
+      }
+      do {  // supp[i]: 0 undecided, 1 selected, 2 suppressed
+        uint8_t ns[4] = {3, 3, 3, 3};  // (R <= 1024, 256 threads; 3: nothing to write)
+        int left = 0;
+        for (int m = 0, i = threadIdx.x; i < R; ++m, i += blockDim.x) {
+          if (supp[i] != 0) continue;
+          bool win = true, dead = false;
+          for (int q = l_off[i]; q < l_off[i + 1]; ++q) {
+            const int j = l_nbr[q];
+            const uint8_t st = supp[j];
+            dead |= st == 1;
+            win &= !(st == 0 && better(j, i));
+          }
+          ns[m & 3] = dead ? 2 : (win ? 1 : 0);
+          left |= !dead && !win;
+        }
+        __syncthreads();  // every state of this round has been read
+        for (int m = 0, i = threadIdx.x; i < R; ++m, i += blockDim.x)
+          if (ns[m & 3] == 1 || ns[m & 3] == 2) supp[i] = ns[m & 3];
+        undecided = __syncthreads_or(left);
+      } while (undecided);
+      // the members, in any order, then each one's rank among them
+      int* n_mem = &n_mem_s;
+      if (threadIdx.x == 0) *n_mem = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < R; i += blockDim.x)
+        if (supp[i] == 1) order[atomicAdd(n_mem, 1)] = i;
+      __syncthreads();
+      const int M = *n_mem;
+      for (int t = threadIdx.x; t < M; t += blockDim.x) {
+        const int i = order[t];
+        int rank = 0;
+        if (M > limit)
+          for (int u = 0; u < M; ++u) rank += better(order[u], i);
+        if (rank < limit) mask[i] = 1;
+      }
+      return;
+    }
+    // Otherwise: the same total order (score descending, index ascending) from a bitonic sorting network over
     // (score, index) pairs in LDS, padded to a power of two with (-inf, index >= R) pairs, which sort behind every
     // region.  R^2 comparisons on the one CU this workgroup owns were 29 us of a launch at R = 512 and 106 us at
     // R = 1024 (4 cycles per wave instruction); the network is R/2 log^2 R compare-exchanges.

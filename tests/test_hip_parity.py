@@ -397,6 +397,28 @@ def test_gate_select_vs_oracle_random():
                 assert torch.equal(got.cpu(), ref), (R, trial, k_active, burst)
 
 
+def test_gate_select_large_map_corner_cases():
+    """Above 64 regions, on a symmetric adjacency, ic_gate_select finds the walk's selections in parallel rounds
+    (ic_gate.h).  Corners: a monotone ridge of scores (as many rounds as the map is long), constant scores (index
+    order alone decides), an ASYMMETRIC adjacency (the kernel notices and takes the sorted walk), a map without edges
+    (every region is a candidate), and several streams with their own k in one launch."""
+    from ironcortex_amd.gate import Gate
+    from ironcortex_amd.wiring import hex_neighbors
+    from oracle import hotpath as O
+    for R in (100, 512, 1024):
+        maps = {"hex": hex_neighbors(R), "directed": [[(i + 1) % R, (i + 7) % R] for i in range(R)], "no-edges": [[] for _ in range(R)],
+                "path": [[j for j in (i - 1, i + 1) if 0 <= j < R] for i in range(R)]}
+        for name, nb in maps.items():
+            gate = Gate(R, nb, {"sensor": 0, "motor": R - 1}).to(DEV)
+            ramp = torch.arange(R, dtype=torch.float32)
+            for what, sc in (("down", -ramp), ("up", ramp), ("flat", torch.zeros(R)), ("rand", gi.det(950 + R, R)),
+                             ("coarse", torch.round(gi.det(951 + R, R) * 3))):
+                for k_active, burst in ((0, 0), (1, 0), (3, 0), (32, 0), (32, R // 8), (R, 0)):
+                    ref = O.gate_select(sc, k_active, burst, nb, 0, R - 1, stable=True)
+                    got = gate.select_k(sc.to(DEV), k_active, burst)
+                    assert torch.equal(got.cpu(), ref), (R, name, what, k_active, burst)
+
+
 # --------------------------------------------------------------------------- router
 def make_router(name, R, d, mode, prec, t):
     from ironcortex_amd.gate import Router
