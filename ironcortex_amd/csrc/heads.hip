@@ -361,6 +361,33 @@ __device__ __forceinline__ void token_rows(const ic_heads_args& a, int lane, int
 }
 
 // mixture-of-facets logits + region heads -> logits, softmax, steering statistics (one workgroup)
+// The activity ballots of a stream's regions, 64 regions per ballot, in ONE memory round trip: every lane requests its
+// byte of all 16 groups (R <= 1024) before the first ballot is formed -- a loop of "load, ballot, use" is one dependent
+// round trip per 64 regions (8 at R = 512, and k_logits_combine went through it once per 256 columns of V).
+// lb: this wave's 16 words in LDS (written by lane 0, read back by the same wave: LDS operations of a wave complete
+// in order).  Bit l of lb[b]: region 64 b + l is on and is not `skip`.  Returns the number of set bits.
+__device__ __forceinline__ int mask_ballots(const uint8_t* mask, int R, int skip, unsigned long long* lb) {
+  const int lane = threadIdx.x & 63;
+  uint8_t m[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const int r = 64 * b + lane;
+    m[b] = (r < R && r != skip) ? mask[r] : (uint8_t)0;
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const unsigned long long x = __ballot(m[b] != 0);
+    cnt += __popcll(x);
+    if (lane == 0) lb[b] = x;
+  }
+  return cnt;
+}
+__device__ __forceinline__ unsigned long long wave_uniform64(unsigned long long x) {
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)x), hi = __builtin_amdgcn_readfirstlane((unsigned int)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* red) {
   constexpr int VPT = 4;  // V <= 1024 (checked on the host)
   const int V = a.V, Kf = a.Kf, R = a.R, tid = threadIdx.x;
@@ -371,11 +398,9 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
   for (int f = 0; f < KF; ++f) zg[f] = f < Kf ? a.z[f] : -INFINITY;
   // number of region heads in the mean: every lane tests its own regions (one round trip for
   // R <= 64), the count comes from ballots -- an exact small integer either way
-  int nwi = 0;
-  for (int base = 0; base < R; base += 64) {
-    const int r = base + (tid & 63);
-    nwi += __popcll(__ballot(r < R && r != a.motor_idx && a.mask[r] != 0));
-  }
+  __shared__ unsigned long long lbal[4][16];
+  unsigned long long* lb = lbal[tid >> 6];
+  const int nwi = mask_ballots(a.mask, R, a.motor_idx, lb);
   const float nw = (float)nwi;
   const int n = R * a.d;
   float g1 = 0.f, g0 = 0.f, sp = 0.f;
@@ -405,9 +430,8 @@ __device__ __forceinline__ void logits_combine(const ic_heads_args& a, float* re
       // large maps: only the rows of the regions in the mean, found 64 at a time by a ballot (every lane of the wave
       // takes part, also those beyond V) and added in the same (row) order -- the rows skipped hold zeros, so the sum
       // is the small-map loop's bit for bit, in R/64 + n_active/8 memory round trips instead of R/8
-      for (int base = 0; base < R; base += 64) {
-        const int rr = base + (tid & 63);
-        unsigned long long bal = __ballot(rr < R && rr != a.motor_idx && a.mask[rr] != 0);
+      for (int base = 0; base < R && (tid & ~63) + 256 * j < V; base += 64) {  // (a wave wholly beyond V has nothing to add)
+        unsigned long long bal = wave_uniform64(lb[base >> 6]);
         while (bal) {
           float pr[8];
 #pragma unroll
@@ -607,13 +631,13 @@ __device__ __forceinline__ void ws_mean_rows(const ic_heads_args& a) {
   if (a.R > kSmallR) {
     // large maps: the active rows found 64 at a time by a ballot, 8 of them in flight, added in row order: the same
     // sums as below (which walks all R rows), in R/64 + n_active/8 round trips instead of R/8
-    const int lane = threadIdx.x & 63;
-    for (int c = threadIdx.x; c < a.d + 255 - (a.d + 255) % 256; c += 256) {  // (whole waves: the ballots need every lane)
+    __shared__ unsigned long long lbal[4][16];
+    unsigned long long* lb = lbal[threadIdx.x >> 6];
+    const int cnt = mask_ballots(a.mask, a.R, -1, lb);
+    for (int c = threadIdx.x; c < a.d + 255 - (a.d + 255) % 256; c += 256) {  // (whole waves: the row walk is wave-uniform)
       float s = 0.f;
-      int cnt = 0;
       for (int base = 0; base < a.R; base += 64) {
-        unsigned long long bal = __ballot(base + lane < a.R && a.mask[base + lane] != 0);
-        cnt += __popcll(bal);
+        unsigned long long bal = wave_uniform64(lb[base >> 6]);
         while (bal) {
           float v[8];
 #pragma unroll
@@ -678,10 +702,11 @@ __device__ __forceinline__ void gemv_on_ws_mean(const ic_heads_args& a, const ic
   constexpr int UB = NX <= 4 ? 8 : (NX <= 8 ? 4 : 2);
   float n_on = 0.f;
   if (a.R > kSmallR) {  // large maps: active rows by ballot, as in ws_mean_rows (same sums)
-    int cnt = 0;
+    __shared__ unsigned long long lbal[4][16];
+    unsigned long long* lb = lbal[wave];
+    const int cnt = mask_ballots(a.mask, a.R, -1, lb);
     for (int base = 0; base < a.R; base += 64) {
-      unsigned long long bal = __ballot(base + lane < a.R && a.mask[base + lane] != 0);
-      cnt += __popcll(bal);
+      unsigned long long bal = wave_uniform64(lb[base >> 6]);
       while (bal) {
         float v[UB][NX];
         bool on[UB];
