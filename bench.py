@@ -336,7 +336,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD[args.config], "per_gpu_batch": B, "global_batch": B * world,
                        "seq_len": T, "params": n_params, "mode": "strict-sequential (reference schedule)",
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       **({"gate_ties": "fresh model of R > 16 regions: all-equal gate scores at inner step 0; exact ties are broken "
+                                        "by the stable order (score desc, index asc), not by the reference's unstable argsort "
+                                        "(declared deviation, DESIGN §3)"} if cfg.R > 16 else {})},
             # (units counted over the EVENT_STEPS steps after the timed region: same tokens, same schedule)
             "region_steps_per_s": units["region_steps_timed"] / elapsed * world,
             "inner_steps_per_s": units["inner_steps_timed"] / elapsed * world,
