@@ -205,7 +205,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dp = None
-    if world > 1:
+    if world > 1 or os.environ.get("IC_FORCE_DP") == "1":  # (IC_FORCE_DP=1 under torch.distributed.run --nproc-per-node 1:
+        # the data-parallel path on RCCL with a one-rank group, to rehearse it on a one-GPU box)
         import torch.distributed as dist
         from ironcortex_amd.parallel import DataParallel
         # RCCL over xGMI; IC_DIST_BACKEND=gloo only to rehearse the N>1 code path on a one-GPU box

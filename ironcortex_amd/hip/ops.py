@@ -95,15 +95,18 @@ class GradCoordinator:
     def offer_early(self, flags: Dict[Callable, Optional[torch.Tensor]], valid: Callable[[], bool]) -> None:
         """flags: launch function of a flagged participant -> the uint8 flags its launch will return at the end of this
         pass (None where it will return None); valid() is asked at the end of the pass, before the launches, whether
-        that still holds (nothing else joined the pass).  Ignored under data parallelism (the flags are OR-ed across
-        ranks on the device there) and unless every flagged participant is covered."""
-        if self.dp is not None or any(launch not in flags for launch, _ in self._flagged):
+        that still holds (nothing else joined the pass).  Ignored unless every flagged participant is covered.  Under
+        data parallelism the flags are OR-ed across ranks right here (one small all-reduce behind the loops, ahead of
+        the backward kernels), so that what reaches pinned memory is already rank-consistent."""
+        if any(launch not in flags for launch, _ in self._flagged):
             return
         parts = [flags[launch] for launch, _ in self._flagged]
         live = [t.reshape(-1) for t in parts if t is not None]
         if not live:
             return
         allf = torch.cat(live)
+        if self.dp is not None:
+            allf = self.dp.any_flags(allf).to(torch.uint8)
         n = allf.numel()
         if self._pinned is None or self._pinned.numel() < n:
             self._pinned = torch.empty(max(n, 1024), dtype=torch.uint8).pin_memory()
@@ -120,16 +123,44 @@ class GradCoordinator:
             flags = [launch() for launch, _ in self._flagged]
             for f in self._finish:
                 f()
-            if self.after_launch is not None:
-                self.after_launch()
             if early is not None and early[0] != [None if t is None else t.numel() for t in flags]:
                 early = None
+            if self.dp is not None:
+                self._exchange_host_flags(early is None)  # (before the arenas' all-reduces join the backend's queue)
+            if self.after_launch is not None:
+                self.after_launch()
             if self.defer:
                 self._held = (flags, early)
             else:
                 self._publish(flags, early)
         finally:
             self._pending = False
+
+    def _exchange_host_flags(self, no_early: bool) -> None:
+        """Data parallel, end of the pass: what only the HOST knows -- which of the parameters outside the arenas hold a
+        gradient on this rank, and whether this rank can use its early flags -- OR-ed across ranks on a side stream
+        that waits for nothing of the backward pass (the host is milliseconds ahead of the device here), into pinned
+        memory; _publish reads it without waiting for the pass's kernels."""
+        self._dpx = None
+        extra = self.extra_params() if self.extra_params is not None else []
+        if not extra or extra[0].device.type != "cuda":
+            return  # (nothing the host alone knows, or a CPU group: _publish takes the device path)
+        device = extra[0].device
+        host = [0 if p.grad is None else 1 for p in extra] + [1 if no_early else 0]
+        if getattr(self, "_side", None) is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device)
+        n = len(host)
+        if getattr(self, "_pinned_x", None) is None or self._pinned_x.numel() < n:
+            self._pinned_x = torch.empty(max(n, 256), dtype=torch.int32).pin_memory()
+            self._pinned_x_in = torch.empty(max(n, 256), dtype=torch.int32).pin_memory()
+        self._pinned_x_in[:n].copy_(torch.tensor(host, dtype=torch.int32))
+        with torch.cuda.stream(self._side):
+            t = self._pinned_x_in[:n].to(device, non_blocking=True)
+            t = self.dp.any_flags(t)
+            self._pinned_x[:n].copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._dpx = (extra, n, ev, t)
 
     def publish(self) -> None:
         """The host read a deferred pass left open (no-op otherwise)."""
@@ -138,11 +169,26 @@ class GradCoordinator:
             self._publish(*held)
 
     def _publish(self, flags, early=None) -> None:
-        if early is not None and self.dp is None:
+        dpx, self._dpx = getattr(self, "_dpx", None), None
+        extra_host = None
+        if self.dp is not None:
+            if dpx is None:
+                early = None
+            else:
+                dpx[2].synchronize()  # (the side stream's exchange: waits for the other ranks' hosts, not for kernels)
+                xh = self._pinned_x[:dpx[1]].tolist()
+                if xh[-1]:  # some rank has no early flags: every rank takes the device path below
+                    early = None
+                else:
+                    extra_host = (dpx[0], xh[:-1])
+        if early is not None:
             early[2].synchronize()  # (long past: the copy was enqueued before the backward kernels)
             host = [bool(v) for v in self._pinned[:early[1]].tolist()]
             if self.check_early:
-                dev_host = torch.cat([t.reshape(-1) for t in flags if t is not None]).bool().tolist()
+                dev_f = torch.cat([t.reshape(-1) for t in flags if t is not None])
+                if self.dp is not None:
+                    dev_f = self.dp.any_flags(dev_f)
+                dev_host = dev_f.bool().tolist()
                 if dev_host != host:
                     raise RuntimeError(f"GradCoordinator: early flags differ from the launches' flags: {host} vs {dev_host}")
             self.early_used += 1
@@ -151,6 +197,10 @@ class GradCoordinator:
                 if t is not None:
                     publish(host[off:off + t.numel()])
                     off += t.numel()
+            if extra_host is not None:
+                for p, h in zip(*extra_host):
+                    if h and p.grad is None:
+                        p.grad = torch.zeros_like(p)
             return
         extra = self.extra_params() if (self.dp is not None and self.extra_params is not None) else []
         parts = [t.reshape(-1) for t in flags if t is not None]
@@ -179,6 +229,7 @@ class GradCoordinator:
         no pass can be in flight there, so a set flag is a stale one.  Returns True if it was."""
         stale, self._pending = self._pending, False
         self._held = self._early = None
+        self._dpx = None
         return stale
 
 

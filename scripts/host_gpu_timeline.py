@@ -8,6 +8,15 @@ from ironcortex_amd import engine as E, training as T
 from bench import make_config
 dev = torch.device("cuda:0")
 MULTI = "--multi" in sys.argv
+DP = "--dp" in sys.argv  # the data-parallel path on RCCL with a one-rank group (identity collectives, real calls)
+dp = None
+if DP:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from ironcortex_amd.parallel import DataParallel
+    dp = DataParallel()
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 cfg = make_config(argv[0] if argv else "10m")
 torch.manual_seed(0); random.seed(0)
@@ -49,6 +58,9 @@ if "--fine" in sys.argv:  # finer host-side markers inside the prologue
     class _W:  # (ctypes functions cannot be wrapped by setattr on the CDLL for cached attribute lookups: patch the engine's view)
         pass
 
+if dp is not None:
+    for nm in ("mean", "any", "gather", "any_flags", "start_arena_reduce", "sync_grads"):
+        wrap(dp, nm, "dp." + nm)
 wrap(opt, "zero_grad", "zero_grad")
 wrap(m, "finalize_grads", "finalize_grads")
 ob = torch.Tensor.backward
@@ -56,14 +68,14 @@ def tb(self, *a, **k):
     mark("backward>"); r = ob(self, *a, **k); mark("backward<"); return r
 torch.Tensor.backward = tb
 for _ in range(4):
-    ic.train_step(m, opt, toks, ic.LossWeights(), dev)
+    ic.train_step(m, opt, toks, ic.LossWeights(), dev, dp=dp)
 torch.cuda.synchronize()
 rows = []
 for rep in range(5):
     marks.clear()
     torch.cuda.synchronize()
     mark("step>")
-    ic.train_step(m, opt, toks, ic.LossWeights(), dev)
+    ic.train_step(m, opt, toks, ic.LossWeights(), dev, dp=dp)
     mark("step<")
     torch.cuda.synchronize()
     t0, e0 = marks[0][1], marks[0][2]

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, q, mode="strict", overlap=True):
+def _rank_main(rank, world, port, q, mode="strict", overlap=True, backend="gloo"):
     try:
         import faulthandler
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,7 +32,11 @@ def _rank_main(rank, world, port, q, mode="strict", overlap=True):
         faulthandler.dump_traceback_later(100, exit=True, file=trace)  # a stuck collective names its line and ends the rank
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":  # RCCL: one rank per GPU, so world == 1 on this box
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         import ironcortex_amd as ic
         from ironcortex_amd.parallel import DataParallel
         from tests.model_cases import load_case, seed_train
@@ -58,7 +62,9 @@ def _rank_main(rank, world, port, q, mode="strict", overlap=True):
         ic.train_step(m1, torch.optim.SGD(m1.parameters(), lr=0.0), shard, ic.LossWeights(), dev)
         g1 = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m1.named_parameters()}
         mark("single-rank step done")
-        # ---- data-parallel run
+        # ---- data-parallel run (early flags verified against the launches' own, OR-ed across ranks)
+        from ironcortex_amd.hip import ops as _ops
+        _ops.GradCoordinator.check_early = True
         dp = DataParallel(overlap=overlap)
         m2 = build()
         dp.broadcast_module(m2)
@@ -75,6 +81,8 @@ def _rank_main(rank, world, port, q, mode="strict", overlap=True):
         out = ic.train_step(m2, opt, shard, ic.LossWeights(), dev, dp=dp)
         assert captured and out["grad_norm"] > 0
         assert len(started) == (1 if overlap else 0) and dp._inflight is None
+        if mode == "strict":  # device-steered loops: which matrices the pass touches is known (and exchanged) before it runs
+            assert m2._coord.early_used >= 1, "the data-parallel pass waited for the device to learn its touched flags"
         mark("dp step done")
         # ---- mean of the single-rank gradients through the group: ONE packed all-reduce (+ one of the flags)
         p1 = dict(m1.named_parameters())
@@ -119,6 +127,28 @@ def _rank_main(rank, world, port, q, mode="strict", overlap=True):
     except BaseException as e:  # noqa: BLE001 -- reported to the parent, which fails the test
         import traceback
         q.put((rank, "fail", traceback.format_exc()[-3000:]))
+
+
+@pytest.mark.parametrize("mode,overlap", [("strict", True), ("strict", False), ("multi", True)])
+def test_dp1_train_step_over_rccl(mode, overlap):
+    """The same exchange through RCCL (backend "nccl"), which wants one GPU per rank: a one-rank group on this box.
+    The collectives are identities there, but every call of the data-parallel path runs on the real backend -- the
+    broadcasts, the asynchronous arena all-reduces started from the end of the backward pass (their work handles and
+    stream ordering), the packed small bucket, the flag exchange -- and the synchronised gradients must equal the
+    single-process run's."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rank_main, args=(0, 1, _free_port(), q, mode, overlap, "nccl"))
+    p.start()
+    try:
+        rank, status, info = q.get(timeout=150)
+    finally:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    assert status == "ok", info
+    print("\n[dp1/rccl]", info)
 
 
 @pytest.mark.parametrize("mode,overlap", [("strict", True), ("strict", False), ("multi", True)])
