@@ -41,6 +41,17 @@ class DataParallel:
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         return out / self.world
 
+    def mean_many(self, ts: List[torch.Tensor]) -> List[torch.Tensor]:
+        """mean() of several float tensors in ONE all-reduce (a small collective costs its latency, not its bytes)."""
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat = flat / self.world
+        out, off = [], 0
+        for t in ts:
+            out.append(flat[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+        return out
+
     def any(self, t: torch.Tensor) -> torch.Tensor:
         out = t.to(torch.int32).contiguous()
         dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.group)

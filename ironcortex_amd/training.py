@@ -170,12 +170,12 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         with torch.no_grad():
             target = gpos.mean(0)
             gains = (gpos - gneg).mean(0)
-            if dp is not None:
-                target, gains = dp.mean(target), dp.mean(gains)
-            if cfg.tau_kappa != 0.0:
-                prec = (model.bank.var[0] + EPS_DIV).reciprocal().mean(-1)
-                if dp is not None:  # region state is rank-local; tau is replicated state: use the mean precision
-                    prec = dp.mean(prec)
+            prec = (model.bank.var[0] + EPS_DIV).reciprocal().mean(-1) if cfg.tau_kappa != 0.0 else None
+            if dp is not None:  # one collective for the three (region state is rank-local, tau is replicated state:
+                # the precision that moves it is the ranks' mean)
+                got = dp.mean_many([target, gains] + ([prec] if prec is not None else []))
+                target, gains, prec = got[0], got[1], (got[2] if prec is not None else None)
+            if prec is not None:
                 target = target + cfg.tau_kappa * (prec - cfg.tau_target_prec)
             new_tau = (1 - 0.01) * tau + 0.01 * target
             for r, ff in enumerate(model.reg_ff):
@@ -218,7 +218,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         if cfg.enable_ff_energy_alignment and model.verify_state is not None:
             Ep, En = E_pos.mean().detach(), E_neg.mean().detach()
             if dp is not None:
-                Ep, En = dp.mean(Ep), dp.mean(En)
+                Ep, En = dp.mean_many([Ep, En])
             model.E_pos_mean = 0.99 * model.E_pos_mean + 0.01 * Ep
             model.E_neg_mean = 0.99 * model.E_neg_mean + 0.01 * En
             model.verify_state.update_tau(0.5 * (model.E_pos_mean + model.E_neg_mean))
@@ -240,8 +240,9 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
                 t = router._edge_tables(model.reg_coords)
                 Hh = H_pos.detach()
                 mp = mask_p.to(H_pos.dtype)
-                if dp is not None:  # every rank applies the whole global batch's nudges
-                    Hh, mp = dp.gather(Hh), dp.gather(mp)
+                if dp is not None:  # every rank applies the whole global batch's nudges (states and masks in one gather)
+                    both = dp.gather(torch.cat([Hh, mp.unsqueeze(-1)], dim=-1))
+                    Hh, mp = both[..., :-1].contiguous(), both[..., -1].contiguous()
                 coef = (1e-3 * gains.clamp_min(0.0))[router.dst_idx].unsqueeze(0) * mp[:, router.dst_idx] * mp[:, router.src_idx]
                 if router.edge_transform_mode != "per_edge":
                     # the reference indexes router.W_edge here, which only per_edge mode defines (gate.py:136-137): it raises
