@@ -62,7 +62,10 @@ enum {
                                from 8192 (stream, region) columns on: below, a tile's nW back-to-back K loops are a
                                latency chain (~50 us at d=256) that the per-edge kernels, reading W[widx[e]] in place
                                for the handful of active senders, undercut (9-45 us) */
-  IC_RF_SHARED_GEMM = 1 << 3, /* with IC_RF_SHARED: the GEMM whatever the number of columns */
+  IC_RF_SHARED_GEMM = 1 << 3, /* with IC_RF_SHARED: the GEMM whatever the number of columns.  With IC_RF_PRECISION too
+                               (by_direction + precision routing, gate.py:274-277 with :292-318) the messages and the
+                               keys of all (stream, edge) pairs are two such GEMMs (from 8192 pairs on, streams laid
+                               out plainly), the queries and the per-destination softmax combine as in per_edge mode */
   IC_RF_FACTORIZED = 1 << 2 /* edge_transform_mode "factorized" (gate.py:150-159,278-281): msg_e = ebias_e * U (w_e * V h_src)
                                with two matrices shared by ALL edges.  Without precision routing the messages of a
                                destination are summed, so M[dst] = U (sum_e ebias_e * w_e * (V h_src_e)): V once per
@@ -236,13 +239,15 @@ typedef struct ic_router_args {
   float* fact_t;            /* [S,R,d] saved: V h of the active senders, zeros elsewhere */
   float* fact_z;            /* [S,R,d] saved: sum over the active in-edges of ebias_e * w_e * t[src_e] */
   uint8_t* fact_dact;       /* [S,R]   saved: 1 if the region has an active in-edge */
-  /* IC_RF_SHARED, optional: workspace of 512 + 2*S*R 32-bit words.  With it (worth it from ~8192 columns on) the forward GEMM walks the
-   * (stream, destination) columns in an order SORTED by which directions have an active in-edge, so that a 32-column
-   * tile skips the matrices none of its columns uses, and the data-gradient GEMM of ic_router_bwd (through .f) walks
-   * the active senders first: the matrix cores only multiply active rows (the results are the same bit for bit:
-   * every column's sums are its own).  Calls sharing one workspace must be ordered on one stream.
-   * NULL: columns in (stream, region) order. */
+  /* IC_RF_SHARED, optional: workspace of shared_ws_len >= 512 + 2*S*R 32-bit words (512 + 2*S*E with IC_RF_PRECISION,
+   * whose GEMM columns are the (stream, edge) pairs).  With it (worth it from ~8192 columns on) the forward GEMM walks
+   * the (stream, destination) columns in an order SORTED by which directions have an active in-edge, so that a
+   * 32-column tile skips the matrices none of its columns uses, and the data-gradient GEMM of ic_router_bwd (through
+   * .f) walks the active senders first: the matrix cores only multiply active rows (the results are the same bit for
+   * bit: every column's sums are its own).  Calls sharing one workspace must be ordered on one stream.
+   * NULL (or too short for the call): columns in (stream, region) order. */
   int32_t* shared_ws;
+  int64_t shared_ws_len;
 } ic_router_args;
 int ic_router_fwd(const ic_router_args* a, ic_stream_t stream);
 

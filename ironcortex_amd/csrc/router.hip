@@ -206,9 +206,10 @@ __device__ __forceinline__ void router_edge_body(const ic_router_args& a, const 
   }
 }
 
+// y0: first (edge | region) row of the grid -- a.E for a launch over the queries alone
 template <int DCH, int PP>
-__global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a) {
-  router_edge_body<DCH, PP>(a, blockIdx.y);
+__global__ __launch_bounds__(256) void k_router_edge_fwd(ic_router_args a, int y0) {
+  router_edge_body<DCH, PP>(a, (int)blockIdx.y + y0);
 }
 
 // ---------------------------------------------------------------- gate + router in one launch
@@ -1069,6 +1070,21 @@ static bool shared_as_gemm(const ic_router_args* a) {
          ((a->flags & IC_RF_SHARED_GEMM) || (long long)a->S * a->R >= min_cols);
 }
 
+// by_direction WITH precision routing: the per-edge messages and keys as two shared-matrix GEMMs over the (stream, edge)
+// pairs?  Same trade as above, counted in pairs -- of which the host only knows the total S * E, not how many carry
+// an active sender.  Measured at R=512, d=256 (scripts/bydir_prec_bench.py, forward in us, GEMMs : edge kernels):
+// 32 of 512 regions on, S = 8 / 16 / 64 (23 k / 47 k / 186 k pairs): 112 : 83, 134 : 119, 314 : 321;
+// 128 on, S = 8 / 64: 143 : 153, 563 : 892.  They meet at ~10 k ACTIVE pairs; kSharedPrecGemmMinPairs is the total from
+// which that holds at the sparse end.  Streams laid out plainly only (in_slot blocks are sized by the region count,
+// which the pseudo-router of the GEMM replaces by the edge count).
+constexpr long long kSharedPrecGemmMinPairs = 131072;
+static bool shared_prec_as_gemm(const ic_router_args* a) {
+  static const long long min_cols = [] { const char* e = getenv("IC_SHARED_GEMM_MIN"); return e && e[0] ? atoll(e) : kSharedPrecGemmMinPairs; }();
+  return (a->flags & IC_RF_SHARED) && (a->flags & IC_RF_PRECISION) && a->E > 0 && !a->in_slot && a->d % 4 == 0 &&
+         a->nW >= 1 && a->nW <= 8 && a->msg && a->keyv &&
+         ((a->flags & IC_RF_SHARED_GEMM) || (long long)a->S * a->E >= min_cols);
+}
+
 // the identity-table router of one of the two row GEMMs of the factorized mode: R self-edges, one shared matrix
 static ic_router_args fact_rows(const ic_router_args* a, const float* W) {
   ic_router_args p = {};
@@ -1076,6 +1092,7 @@ static ic_router_args fact_rows(const ic_router_args* a, const float* W) {
   p.dst_off = a->fact_iota; p.src = a->fact_iota; p.widx = a->fact_zero;
   p.W = W; p.ebias = a->fact_ones;
   p.shared_ws = a->shared_ws;  // (the column sort of the row GEMMs: active rows only)
+  p.shared_ws_len = a->shared_ws_len;
   return p;
 }
 
@@ -1148,11 +1165,32 @@ extern "C" int ic_router_fwd(const ic_router_args* a, ic_stream_t stream) {
       if (rows_env == 8 || rows_env == 16 || rows_env == 32) pp = rows_env / 8;
     }
     const int nslp = ic_ceil_div(a->d, kRowsPerBlock * pp);
-    const dim3 ge(nslp, a->E + a->R, edge_nz(a->S, (int64_t)nslp * (a->E + a->R)));
+    // Shared matrices (by_direction + precision): messages and keys of all (stream, edge) pairs as TWO GEMMs on the
+    // matrix cores -- the shared-matrix forward over E pseudo-destinations with one in-edge each (identity edge table:
+    // dst_off NULL), so its output rows are msg[s, e, :] / keyv[s, e, :]; the edge kernel then only forms the queries.
+    int y0 = 0;
+    if (shared_prec_as_gemm(a)) {
+      ic_router_args p = {};
+      p.S = a->S; p.R = a->E; p.d = a->d; p.E = a->E; p.flags = IC_RF_SHARED | (1 << 30) /* idle rows are not written */; p.nW = a->nW;
+      p.src = a->src; p.widx = a->widx;  // (dst_off NULL: column (s, e) has the one in-edge e)
+      p.H = a->H; p.mask_prev = a->mask_prev;
+      p.H_sstride = a->H_sstride ? a->H_sstride : (int64_t)a->R * a->d;
+      p.mask_sstride = a->mask_sstride ? a->mask_sstride : (int64_t)a->R;
+      p.shared_ws = a->shared_ws; p.shared_ws_len = a->shared_ws_len;
+      p.W = a->W; p.ebias = a->ebias; p.M = a->msg;
+      int rc2 = ic_router_shared_fwd_launch(&p, st);
+      if (rc2) return rc2;
+      p.W = a->key_W; p.ebias = nullptr; p.M = a->keyv;  // (keys carry no edge bias)
+      rc2 = ic_router_shared_fwd_launch(&p, st);
+      if (rc2) return rc2;
+      y0 = a->E;
+    }
+    const int ny = a->E + a->R - y0;
+    const dim3 ge(nslp, ny, edge_nz(a->S, (int64_t)nslp * ny));
     IC_DISPATCH_DCH(a->d, {
-      if (pp == 4) IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 4>), ge, dim3(256), 0, st, *a));
-      else if (pp == 2) IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 2>), ge, dim3(256), 0, st, *a));
-      else IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 1>), ge, dim3(256), 0, st, *a));
+      if (pp == 4) IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 4>), ge, dim3(256), 0, st, *a, y0));
+      else if (pp == 2) IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 2>), ge, dim3(256), 0, st, *a, y0));
+      else IC_TIMED(IC_KID_router_edge_fwd, st, hipLaunchKernelGGL((k_router_edge_fwd<DCH, 1>), ge, dim3(256), 0, st, *a, y0));
     });
     const dim3 gcomb(ic_ceil_div(a->S * a->R, 4));
     if (a->d <= 256) IC_TIMED(IC_KID_router_combine, st, hipLaunchKernelGGL(k_router_combine<1>, gcomb, dim3(256), 0, st, *a));

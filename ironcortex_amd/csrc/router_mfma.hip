@@ -39,6 +39,16 @@ __device__ __forceinline__ void mfma_chunk(const float (*As)[kTK + 1], const flo
 // columns of that pattern (LDS atomic) on top of a range the workgroup reserves with one global atomic per non-empty
 // bin.  The order INSIDE a pattern is whatever the atomics make it: it does not matter, every column's result is its
 // own and is written to the column's own place.
+// Edge tables of the GEMM's columns.  dst_off == nullptr: column r has exactly ONE in-edge, edge r (the per-edge
+// products of precision routing: columns are (stream, edge) pairs, router.hip shared_prec_fwd); ebias == nullptr: 1.
+__device__ __forceinline__ int col_edges_lo(const ic_router_args& a, int r) { return a.dst_off ? a.dst_off[r] : r; }
+__device__ __forceinline__ int col_edges_hi(const ic_router_args& a, int r) { return a.dst_off ? a.dst_off[r + 1] : r + 1; }
+__device__ __forceinline__ float col_edge_bias(const ic_router_args& a, int e) { return a.ebias ? a.ebias[e] : 1.f; }
+
+// library-internal flag of the pseudo-routers built in router.hip: columns without an active in-edge are NOT written
+// (per-edge message / key rows that nobody reads), instead of written as zeros (the router's output proper)
+constexpr int kSkipIdleCols = 1 << 30;
+
 constexpr int kPatBins = 256, kPermHdr = 512, kSortMinCols = 64;  // (below two tiles there is nothing to sort; the caller decides from where it pays)
 __global__ __launch_bounds__(256) void k_shared_pattern(ic_router_args a, int mode, const int32_t* bwd_slot) {
   __shared__ int hist[kPatBins];
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(256) void k_shared_pattern(ic_router_args a, int mo
     const int s = n / a.R, r = n % a.R;
     int pat = 0;
     if (mode == 0) {
-      for (int e = a.dst_off[r]; e < a.dst_off[r + 1]; ++e)
+      for (int e = col_edges_lo(a, r); e < col_edges_hi(a, r); ++e)
         if (prev_on(a, s, a.src[e])) pat |= 1 << a.widx[e];
       pat &= kPatBins - 1;
     } else {
@@ -103,6 +113,7 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
   __shared__ float tscale[kMaxShared][TN];
   __shared__ int any_k[kMaxShared];
   __shared__ int tcol[TN];
+  __shared__ int cact[TN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = a.d, N = a.S * a.R;
   const int row0 = blockIdx.x * kTM, col0 = blockIdx.y * TN;
@@ -111,6 +122,7 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
     int n = col0 + tid;
     if (perm && n < N) n = perm[n];
     tcol[tid] = (unsigned)n < (unsigned)N ? n : -1;
+    cact[tid] = 0;
   }
   for (int idx = tid; idx < kMaxShared * TN; idx += 256) {
     tsrc[idx / TN][idx % TN] = -1;
@@ -123,12 +135,13 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
     const int c = idx % TN, i = idx / TN, n = tcol[c];
     if (n >= 0) {
       const int s = n / a.R, r = n % a.R;
-      for (int e = a.dst_off[r] + i; e < a.dst_off[r + 1]; e += kMaxShared) {
+      for (int e = col_edges_lo(a, r) + i; e < col_edges_hi(a, r); e += kMaxShared) {
         const int k = a.widx[e], sr = a.src[e];
         if (k >= 0 && k < a.nW && prev_on(a, s, sr)) {
           tsrc[k][c] = sr;
-          tscale[k][c] = a.ebias[e];
+          tscale[k][c] = col_edge_bias(a, e);
           any_k[k] = 1;  // (same value from every writer)
+          cact[c] = 1;
         }
       }
     }
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(256) void k_router_shared_fwd_mfma(ic_router_args a
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int n = tcol[nb * kTN + (lane & 31)];
-    if (n >= 0) {
+    if (n >= 0 && (!(a.flags & kSkipIdleCols) || cact[nb * kTN + (lane & 31)])) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = row0 + wave * 32 + 8 * q + 4 * (lane >> 5);
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(256) void k_router_shared_dgrad_mfma(ic_router_bwd_
 // caller brought one and the map is large enough for the two small launches to pay; *perm stays null otherwise.
 static int shared_sort(const ic_router_args* a, int mode, const int32_t* bwd_slot, hipStream_t st, const int32_t** perm) {
   const int N = a->S * a->R;
-  if (!a->shared_ws || N < kSortMinCols || a->nW > 8) return IC_OK;
+  if (!a->shared_ws || N < kSortMinCols || a->nW > 8 || a->shared_ws_len < (long long)kPermHdr + 2ll * N) return IC_OK;
   if (hipMemsetAsync(a->shared_ws, 0, kPermHdr * sizeof(int32_t), st) != hipSuccess) {
     ic_set_error("ic_router: hipMemsetAsync of the column-sort counters failed");
     return IC_ELAUNCH;

@@ -535,15 +535,17 @@ def _router_args(spec: RouterSpec, T: Dict[str, torch.Tensor], P: Dict[str, torc
         a.W = P["W"].data_ptr()
     if spec.precision:
         a.key_W, a.query_W, a.raw_P = P["key_W"].data_ptr(), P["query_W"].data_ptr(), P["raw_P"].data_ptr()
-    elif (spec.shared_gemm or spec.factorized) and SHARED_SORT and S * spec.R >= SHARED_SORT_MIN:
+    # the GEMM's columns: (stream, region) pairs; (stream, edge) pairs for the messages / keys of precision routing
+    cols = S * (spec.E if spec.precision else spec.R)
+    if (spec.shared_gemm or (spec.factorized and not spec.precision)) and SHARED_SORT and cols >= SHARED_SORT_MIN:
         # workspace of the column sort (ic_router_args.shared_ws): one per (columns, device, stream) -- calls that share
         # one are ordered on that stream -- reused by every call (forward and data gradient)
         dev = T["dst_off"].device
-        key = (S * spec.R, dev, torch.cuda.current_stream(dev).cuda_stream)
+        key = (cols, dev, torch.cuda.current_stream(dev).cuda_stream)
         ws = _SHARED_WS.get(key)
         if ws is None:
-            ws = _SHARED_WS[key] = torch.zeros(512 + 2 * S * spec.R, dtype=torch.int32, device=dev)
-        a.shared_ws = ws.data_ptr()
+            ws = _SHARED_WS[key] = torch.zeros(512 + 2 * cols, dtype=torch.int32, device=dev)
+        a.shared_ws, a.shared_ws_len = ws.data_ptr(), ws.numel()
     return a
 
 

@@ -327,15 +327,21 @@ def test_router_by_direction_mfma_vs_oracle(R, S, d, gemm, monkeypatch):
     PL.flush(_TAG[0])
 
 
-@pytest.mark.parametrize("R,S,d", [(36, 4, 256), (10, 3, 48)])
-def test_router_by_direction_precision_vs_oracle(R, S, d):
+@pytest.mark.parametrize("gemm", [False, True, "sorted"], ids=["edge-kernels", "gemm", "gemm-sorted"])
+@pytest.mark.parametrize("R,S,d", [(36, 4, 256), (10, 3, 48), (36, 9, 64)])
+def test_router_by_direction_precision_vs_oracle(R, S, d, gemm, monkeypatch):
     """by_direction WITH precision routing (gate.py:274-277 with :292-318): messages and keys through the six shared
-    matrices (the per-edge precision kernels read W[widx[e]] / key_W[widx[e]] / raw_P[widx[e]] in place), per-region
-    queries, softmax-combined per destination -- output and every gradient against the per-stream oracle, bit-identical
-    from run to run."""
+    matrices -- by the per-edge precision kernels reading W[widx[e]] / key_W[widx[e]] / raw_P[widx[e]] in place (the
+    library's choice below 8192 (stream, edge) pairs), or as TWO shared-matrix GEMMs over the pairs (IC_RF_SHARED_GEMM
+    here; with the pairs sorted by direction in the third variant) -- per-region queries, softmax-combined per
+    destination: output and every gradient against the per-stream oracle, bit-identical from run to run."""
     from ironcortex_amd.gate import Router
+    from ironcortex_amd.hip import ops
     from ironcortex_amd.wiring import hex_axial_coords, hex_neighbors
     from oracle import hotpath as O
+    monkeypatch.setattr(ops, "SHARED_GEMM_ALWAYS", bool(gemm))
+    monkeypatch.setattr(ops, "SHARED_SORT", gemm == "sorted")
+    monkeypatch.setattr(ops, "SHARED_SORT_MIN", 64)
     seed = 8500 + R + S
     nb = hex_neighbors(R)
     coords = hex_axial_coords(R)
@@ -367,6 +373,19 @@ def test_router_by_direction_precision_vs_oracle(R, S, d):
         assert torch.equal(a_, b_), "not reproducible from run to run"
     M, gH, gW, gK, gQ, gP, gbc, gbs = runs[0]
     assert torch.all(M[S - 1] == 0) and float(M.abs().sum()) > 0
+    from ironcortex_amd import hip  # which kernels served the forward: the variant asked for
+    hip.prof_select("")
+    hip.prof_enable(True)
+    hip.prof_read()
+    try:
+        with torch.no_grad():
+            router.route(H.to(DEV), mask.to(torch.uint8).to(DEV), coords.to(DEV))
+        torch.cuda.synchronize()
+        prof = hip.prof_read()
+    finally:
+        hip.prof_enable(False)
+    assert ("router_mfma" in prof) == bool(gemm), sorted(prof)
+    assert prof.get("router_mfma", (0, 0))[0] == (0 if not gemm else (6 if gemm == "sorted" else 2)), prof  # (2 GEMMs [+ 2 sorts of 2 launches])
     leaf = lambda x: x.clone().requires_grad_(True)
     P = {"W_dir": [leaf(W_dir[k]) for k in range(6)], "key_W": [leaf(K_dir[k]) for k in range(6)], "raw_P": [leaf(rawP[k]) for k in range(6)],
          "query_W": [leaf(Q[r]) for r in range(R)], "W_reg": t["W_reg"], "beta_cos": leaf(t["beta_cos"]), "beta_sin": leaf(t["beta_sin"])}
@@ -374,7 +393,7 @@ def test_router_by_direction_precision_vs_oracle(R, S, d):
     Mc = torch.stack([O.router_messages(P, Hc[s], mask[s], coords, nb, mode="by_direction", precision=True)[0] for s in range(S)])
     (Mc * gM).sum().backward()
     z = lambda xs: torch.stack([x.grad if x.grad is not None else torch.zeros_like(x) for x in xs])
-    _TAG[0] = f"by_direction-precision/R{R}/S{S}/d{d}"
+    _TAG[0] = f"by_direction-precision-{gemm}/R{R}/S{S}/d{d}"
     close(M, Mc, what="M")
     gclose(gH, Hc.grad, what="g.H")
     gclose(gW, z(P["W_dir"]), what="g.W_dir")
