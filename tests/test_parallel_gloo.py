@@ -42,6 +42,7 @@ def _worker(rank, world, port, q):
             "w": lin.weight.grad.clone(), "bias": lin.bias.grad.clone(), "a": a.grad.clone(), "b": b.grad.clone(),
             "c_none": c.grad is None, "mean": dp.mean(torch.tensor([float(rank)])),
             "any": dp.any(torch.tensor([rank == 1, False])), "gather": dp.gather(torch.full((2, 3), float(rank))),
+            "many": dp.mean_many([torch.full((3,), float(rank)), torch.tensor(2.0 * rank), torch.full((2, 2), 4.0 - rank)]),
         }
         q.put((rank, out))
     finally:
@@ -68,6 +69,9 @@ def test_dp_exchange_world2():
         assert o["c_none"]                                          # None everywhere stays None
         assert torch.allclose(o["mean"], torch.tensor([0.5]))
         assert o["any"].tolist() == [True, False]
+        many = o["many"]  # one all-reduce for several tensors, shapes kept
+        assert torch.equal(many[0], torch.full((3,), 0.5)) and many[1].shape == () and float(many[1]) == 1.0
+        assert torch.equal(many[2], torch.full((2, 2), 3.5))
         assert torch.equal(o["gather"], torch.cat([torch.zeros(2, 3), torch.ones(2, 3)]))
     # replicas end identical
     for k in ("w", "bias", "a", "b"):
