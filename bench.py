@@ -27,6 +27,15 @@ import random
 import sys
 import time
 
+# Data-parallel runs: two hardware queues per process instead of HIP's four.  A train_step is one long chain of dependent
+# launches on one stream plus a handful of collectives on the backend's; with the default four queues the loops of a
+# data-parallel step ran 0.9-1.3 ms longer than the same graph without a process group (one-rank RCCL group,
+# scripts/host_gpu_timeline.py --dp: step 15.3 ms, with two queues 14.0 ms, with one 15.6 ms; without data parallelism
+# the setting changes nothing).  Must be in the environment before the HIP runtime starts.  IC_HW_QUEUES=<n> chooses
+# another count, IC_HW_QUEUES=keep leaves the environment's GPU_MAX_HW_QUEUES alone (the GPU boxes export 4).
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("IC_FORCE_DP") == "1") and os.environ.get("IC_HW_QUEUES") != "keep":
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("IC_HW_QUEUES", "2")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

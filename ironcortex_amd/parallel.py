@@ -52,6 +52,43 @@ class DataParallel:
             off += t.numel()
         return out
 
+    # asynchronous forms: the collective is queued on the backend's stream (behind what the current stream has queued so
+    # far) and the caller goes on; result() waits for it (the current stream does, not the host) and finishes the value.
+    # train_step issues them as soon as their inputs exist and picks the results up after the backward pass, so that
+    # no small collective -- a latency and a meeting point of the ranks -- sits in the main stream's chain.
+    def mean_many_async(self, ts: List[torch.Tensor]):
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        shapes = [(t.numel(), t.shape) for t in ts]
+
+        def result() -> List[torch.Tensor]:
+            work.wait()
+            mean, out, off = flat / self.world, [], 0
+            for n, shp in shapes:
+                out.append(mean[off:off + n].view(shp))
+                off += n
+            return out
+        return result
+
+    def gather_async(self, t: torch.Tensor):
+        t = t.detach().contiguous()
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        work = dist.all_gather(parts, t, group=self.group, async_op=True)
+
+        def result() -> torch.Tensor:
+            work.wait()
+            return torch.cat(parts, dim=0)
+        return result
+
+    def any_async(self, t: torch.Tensor):
+        out = t.to(torch.int32).contiguous()
+        work = dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+
+        def result() -> torch.Tensor:
+            work.wait()
+            return out.bool()
+        return result
+
     def any(self, t: torch.Tensor) -> torch.Tensor:
         out = t.to(torch.int32).contiguous()
         dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.group)

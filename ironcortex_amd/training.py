@@ -162,6 +162,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     # ---- FF per-region losses on the final states (training.py:120-156), batched over regions
     ff_loss = zero
     gains = None
+    ff_stats = e_stats = heb_gather = fired_any = None  # (data parallel: collectives in flight, see below)
     if cfg.enable_forward_forward:
         gpos = ops.GoodnessFn.apply(H_pos) - lam_s * surprise  # [B,R]
         gneg = ops.GoodnessFn.apply(H_neg) - lam_s * surprise
@@ -171,16 +172,21 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
             target = gpos.mean(0)
             gains = (gpos - gneg).mean(0)
             prec = (model.bank.var[0] + EPS_DIV).reciprocal().mean(-1) if cfg.tau_kappa != 0.0 else None
-            if dp is not None:  # one collective for the three (region state is rank-local, tau is replicated state:
-                # the precision that moves it is the ranks' mean)
-                got = dp.mean_many([target, gains] + ([prec] if prec is not None else []))
-                target, gains, prec = got[0], got[1], (got[2] if prec is not None else None)
-            if prec is not None:
-                target = target + cfg.tau_kappa * (prec - cfg.tau_target_prec)
-            new_tau = (1 - 0.01) * tau + 0.01 * target
-            for r, ff in enumerate(model.reg_ff):
-                ff.tau = new_tau[r]
-            model.gate.gain_ema.mul_(0.9).add_((1.0 - 0.9) * gains)
+
+            def apply_ff_stats(target, gains, prec):
+                if prec is not None:
+                    target = target + cfg.tau_kappa * (prec - cfg.tau_target_prec)
+                new_tau = (1 - 0.01) * tau + 0.01 * target
+                for r, ff in enumerate(model.reg_ff):
+                    ff.tau = new_tau[r]
+                model.gate.gain_ema.mul_(0.9).add_((1.0 - 0.9) * gains)
+
+            if dp is not None:  # one collective for the three (region state is rank-local, tau is replicated state: the
+                # precision that moves it is the ranks' mean), started here and picked up after the backward pass:
+                # tau and gain_ema are next used by the NEXT step (this step's losses hold their own copy of tau)
+                ff_stats = dp.mean_many_async([target, gains] + ([prec] if prec is not None else []))
+            else:
+                apply_ff_stats(target, gains, prec)
 
     # ---- RTD on the negative stream's motor state
     motor = model.io_idxs["motor"]
@@ -217,11 +223,16 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
         verifier_loss = ff_energy_loss(E_pos, E_neg, tau=tau_v)
         if cfg.enable_ff_energy_alignment and model.verify_state is not None:
             Ep, En = E_pos.mean().detach(), E_neg.mean().detach()
+
+            def apply_e_stats(Ep, En):
+                model.E_pos_mean = 0.99 * model.E_pos_mean + 0.01 * Ep
+                model.E_neg_mean = 0.99 * model.E_neg_mean + 0.01 * En
+                model.verify_state.update_tau(0.5 * (model.E_pos_mean + model.E_neg_mean))
+
             if dp is not None:
-                Ep, En = dp.mean_many([Ep, En])
-            model.E_pos_mean = 0.99 * model.E_pos_mean + 0.01 * Ep
-            model.E_neg_mean = 0.99 * model.E_neg_mean + 0.01 * En
-            model.verify_state.update_tau(0.5 * (model.E_pos_mean + model.E_neg_mean))
+                e_stats = dp.mean_many_async([Ep, En])
+            else:
+                apply_e_stats(Ep, En)
     else:
         E_pos, E_neg = torch.zeros(B, device=device), torch.zeros(B, device=device)
         verifier_loss = zero
@@ -230,10 +241,22 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
     coord = model._coord
     if dp is not None:
         dp.attach(model)  # None-ness of every gradient made rank-consistent inside the backward's one host read
+        # what the updates after the backward pass need from the other ranks only depends on the forward: asked for now,
+        # it travels while the backward runs
+        with torch.no_grad():
+            if cfg.enable_forward_forward and model.router.E > 0:
+                heb_gather = dp.gather_async(torch.cat([H_pos.detach(), mask_p.to(H_pos.dtype).unsqueeze(-1)], dim=-1))
+            fired_any = dp.any_async(mask_n.any(dim=0))
     coord.defer = True  # the backward's one host read waits until the updates below have been enqueued behind it
     try:
         total.backward()
         with torch.no_grad():
+            if ff_stats is not None:  # (data parallel: the means asked for before the pass)
+                got = ff_stats()
+                gains = got[1]
+                apply_ff_stats(got[0], got[1], got[2] if len(got) > 2 else None)
+            if e_stats is not None:
+                apply_e_stats(*e_stats())
             # Hebbian nudges on edges whose two ends were active in a positive sample (training.py:147-156,240-243)
             if gains is not None and model.router.E > 0:
                 router = model.router
@@ -241,7 +264,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
                 Hh = H_pos.detach()
                 mp = mask_p.to(H_pos.dtype)
                 if dp is not None:  # every rank applies the whole global batch's nudges (states and masks in one gather)
-                    both = dp.gather(torch.cat([Hh, mp.unsqueeze(-1)], dim=-1))
+                    both = heb_gather()
                     Hh, mp = both[..., :-1].contiguous(), both[..., -1].contiguous()
                 coef = (1e-3 * gains.clamp_min(0.0))[router.dst_idx].unsqueeze(0) * mp[:, router.dst_idx] * mp[:, router.src_idx]
                 if router.edge_transform_mode != "per_edge":
@@ -257,7 +280,7 @@ def train_step(model: CortexReasoner, optimizer: torch.optim.Optimizer, clean_to
                         model._units[14:16] += torch.stack([torch.ones((), device=coef.device), (coef != 0).any(0).sum().float()])
             active_frac = mask_n.float().mean()
             fired = mask_n.any(dim=0)
-            model.gate.update_homeo(dp.any(fired) if dp is not None else fired)
+            model.gate.update_homeo(fired_any() if dp is not None else fired)
             scalars = [t.detach().float().reshape(()) for t in (
                 ff_loss, rtd_loss, denoise_loss, critic_loss, verifier_loss, E_pos.mean(), E_neg.mean(), rtd_acc,
                 denoise_acc, active_frac, ce_loss, total)]

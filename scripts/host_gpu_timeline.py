@@ -10,6 +10,12 @@ dev = torch.device("cuda:0")
 MULTI = "--multi" in sys.argv
 DP = "--dp" in sys.argv  # the data-parallel path on RCCL with a one-rank group (identity collectives, real calls)
 dp = None
+if "--pg" in sys.argv or "--pg-each" in sys.argv:  # the process group and its communicator exist, the step does not use them (A/B: what RCCL's mere presence costs)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29542")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    _t = torch.ones(4, device=dev); dist.all_reduce(_t); torch.cuda.synchronize()
 if DP:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
@@ -73,6 +79,8 @@ torch.cuda.synchronize()
 rows = []
 for rep in range(5):
     marks.clear()
+    if "--pg-each" in sys.argv:  # one collective between the steps, none inside
+        dist.all_reduce(_t)
     torch.cuda.synchronize()
     mark("step>")
     ic.train_step(m, opt, toks, ic.LossWeights(), dev, dp=dp)
