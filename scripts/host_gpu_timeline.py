@@ -65,6 +65,13 @@ if "--fine" in sys.argv:  # finer host-side markers inside the prologue
         pass
 
 if dp is not None:
+    if "--dp-sync" in sys.argv:  # experiment: the first collective of a step waits (on the host) for the loops to finish,
+        # so nothing sits on the backend's queue while the loops run (DESIGN rule xiii)
+        _mm = dp.mean_many_async
+        def _mm_sync(ts):
+            torch.cuda.current_stream().synchronize()
+            return _mm(ts)
+        dp.mean_many_async = _mm_sync
     for nm in ("mean", "any", "gather", "any_flags", "start_arena_reduce", "sync_grads"):
         wrap(dp, nm, "dp." + nm)
 wrap(opt, "zero_grad", "zero_grad")
