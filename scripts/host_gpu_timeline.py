@@ -80,6 +80,9 @@ ob = torch.Tensor.backward
 def tb(self, *a, **k):
     mark("backward>"); r = ob(self, *a, **k); mark("backward<"); return r
 torch.Tensor.backward = tb
+if "--own-stream" in sys.argv:  # experiment: everything on a stream of the pool instead of the default (null) stream
+    _own = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(_own)
 for _ in range(4):
     ic.train_step(m, opt, toks, ic.LossWeights(), dev, dp=dp)
 torch.cuda.synchronize()
