@@ -568,6 +568,10 @@ __global__ __launch_bounds__(256) void k_router_comb_bwd(ic_router_bwd_args b, i
 
 // ---------------------------------------------------------------- backward: transposed GEMVs
 // blockIdx.y < E: W_e^T (ebias*gmsg) + Key_e^T gkey -> slab;  >= E: Q_r^T gq -> slab_q.
+// Which (stream, edge | query) rows carry a gradient is read from the activity bytes k_router_comb_bwd has just
+// written (tape_eact == the sender's previous mask under every stream addressing, tape_qact): ONE load that depends
+// on nothing but the kernel arguments, where src[e] -> in_slot[s] -> mask was a chain of three -- most workgroups
+// of a large map only run this test.
 template <int DCH, int RPW>
 __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   const ic_router_args& a = b.f;
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   bool any = false;  // streams are split over gridDim.z as in the region backward
   for (int sc = blockIdx.z; sc < a.S && !any; sc += 64 * gridDim.z) {
     const int s = sc + lane * gridDim.z;
-    any = __ballot(s < a.S && (is_q ? (b.tape_qact[(size_t)s * sk * a.R + r] != 0) : prev_on(b, s, src))) != 0;
+    any = __ballot(s < a.S && (is_q ? b.tape_qact[(size_t)s * sk * a.R + r] : b.tape_eact[(size_t)s * sk * a.E + e]) != 0) != 0;
   }
   if (!any) return;
   const float* W = is_q ? a.query_W + (size_t)r * dd : a.W + (size_t)a.widx[e] * dd;
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256) void k_router_mat_bwd(ic_router_bwd_args b) {
   const int SE = a.S * sk * a.E, SR = a.S * sk * a.R;
   for (int s = blockIdx.z; s < a.S; s += gridDim.z) {
     const int vs = s * sk;
-    const bool act = is_q ? (b.tape_qact[(size_t)vs * a.R + r] != 0) : (prev_on(b, s, src));
+    const bool act = (is_q ? b.tape_qact[(size_t)vs * a.R + r] : b.tape_eact[(size_t)vs * a.E + e]) != 0;
     if (!act) continue;  // block-uniform
     RowFrag<DCH> h, acc;
     zero_frag(acc);
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(256) void k_router_matT_bwd(ic_router_bwd_args b) {
   for (int sc = blockIdx.z; sc < a.S; sc += 64 * nz) {
     const int sl = sc + lane * nz;
     unsigned long long act =
-        __ballot(sl < a.S && (is_q ? (b.tape_qact[(size_t)sl * sk * a.R + r] != 0) : prev_on(b, sl, src)));
+        __ballot(sl < a.S && (is_q ? b.tape_qact[(size_t)sl * sk * a.R + r] : b.tape_eact[(size_t)sl * sk * a.E + e]) != 0);
     if (!act) continue;
     if (!loaded) {  // (wave-uniform)
 #pragma unroll
